@@ -1,0 +1,149 @@
+/*
+ * psim.h -- C ABI of libpsim_hip.so, the MI355X (gfx950) implementation of the
+ * per-timestep physics step of NeoLorenzo/Particle-Simulator.
+ *
+ * The reference has no FFI: its boundary is the Python class ParticleSystem
+ * (particle_system.py:339-804) as main.py drives it.  Each entry point below
+ * names the reference interface it stands in for (file:line into the reference
+ * checkout); psim_amd/particle_system.py binds them with ctypes and re-creates
+ * that class on top.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success and a negative code on failure, with the message available from
+ * psim_last_error() (the reference raises Python exceptions; the binding turns
+ * codes back into exceptions).  One context per device; a context is not
+ * re-entrant; all calls are synchronous (state is complete on return).
+ * Host arrays use the reference's layouts: positions / velocities /
+ * accelerations (n,2) float64 C-contiguous, masses / inverse_masses /
+ * temperatures (n,1) float64, radii (n,1) int64 (particle_system.py:370-376).
+ */
+#ifndef PSIM_H
+#define PSIM_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSIM_OK 0
+#define PSIM_ERR_INVALID (-1)   /* bad argument / handle */
+#define PSIM_ERR_RUNTIME (-2)   /* HIP failure, node-pool overflow, ... */
+
+/* stage mask bits for psim_config.stage_mask (all set = the reference's update()) */
+#define PSIM_STAGE_COLLISIONS 1
+#define PSIM_STAGE_CONDUCTION 2
+#define PSIM_STAGE_COOLING 4
+#define PSIM_STAGE_WALLS 8
+#define PSIM_STAGE_EXPLOSIONS 16
+#define PSIM_STAGE_ALL 31
+
+/* The "simulation" section of config.json (config.json:8-24) plus the values
+ * ParticleSystem.__init__ derives from it (particle_system.py:358-397) and the
+ * constants.py values the step reads (WIDTH/HEIGHT via bounds, COLOR_MAX_TEMP). */
+typedef struct psim_config {
+    double bounds_w, bounds_h;        /* main.py:140, constants.py:15-16 */
+    double gravity_constant;          /* config.json:12 */
+    double softening;                 /* config.json:13 softening_factor */
+    double theta;                     /* config.json:14 barnes_hut_theta */
+    double heat_coeff;                /* config.json:17 heat_transfer_coefficient */
+    double restitution;               /* config.json:18 */
+    double pos_correct;               /* config.json:20 position_correction_factor (default 1.0) */
+    double explosion_eff;             /* config.json:22 explosion_efficiency (default 0.1) */
+    double damping;                   /* config.json:23 thermal_damping_factor (default 0.0) */
+    double explode_temp;              /* constants.py:33 COLOR_MAX_TEMP */
+    int32_t cell_size, grid_w, grid_h;/* particle_system.py:381-390 */
+    int32_t solver_iterations;        /* config.json:21 collision_solver_iterations (default 1) */
+    int32_t stage_mask;               /* PSIM_STAGE_*; the reference has no such switch */
+    int32_t walk_mode;                /* 0 = wave-cooperative tree walk, 1 = one lane per particle */
+    int32_t debug;                    /* 1 = keep the per-step contact log and delta-temperature array */
+    int32_t reserved;
+} psim_config;
+
+typedef struct psim_context psim_context;
+
+/* replaces: ParticleSystem.__init__ up to the state draws (particle_system.py:355-368).
+ * device_ordinal selects the HIP device for every later call on the context. */
+int psim_create(const psim_config* cfg, int device_ordinal, psim_context** out);
+int psim_destroy(psim_context* ctx);
+
+/* replaces: re-reading self.config each step (particle_system.py:430,462,555,673) */
+int psim_set_config(psim_context* ctx, const psim_config* cfg);
+
+/* replaces: the state arrays created in __init__ (particle_system.py:370-376).
+ * vel / acc may be NULL (zeros).  inverse_masses are derived as 1.0 / masses. */
+int psim_upload(psim_context* ctx, int64_t n, const double* positions, const double* velocities,
+                const double* accelerations, const double* masses, const double* temperatures,
+                const int64_t* radii);
+
+/* replaces: reading the public state arrays after a step (particle_system.py:594-624, 716-725).
+ * Any pointer may be NULL.  Arrays must hold psim_num_particles() rows. */
+int psim_download(psim_context* ctx, double* positions, double* velocities, double* accelerations,
+                  double* masses, double* inverse_masses, double* temperatures, int64_t* radii);
+
+int64_t psim_num_particles(psim_context* ctx);   /* particle_system.py:725 num_particles */
+
+/* replaces: ParticleSystem._calculate_gravity() on a tree of the current positions
+ * (particle_system.py:409-437; main.py:151 primes a(0) with it right after __init__) */
+int psim_prime_gravity(psim_context* ctx);
+
+/* replaces: ParticleSystem.update() called k_steps times (particle_system.py:518-563) */
+int psim_step(psim_context* ctx, int64_t k_steps);
+
+/* replaces: get_total_kinetic_energy / get_total_potential_energy /
+ * get_total_thermal_energy (particle_system.py:765-804); out[0..2] = KE, PE, TE,
+ * out[3..4] = total momentum (sum m v), which the reference does not report. */
+int psim_energies(psim_context* ctx, double out[5]);
+
+/* replaces: .pe_gain_collisions / .ke_loss_collisions / .heat_generated_collisions
+ * of the last step (particle_system.py:472-474) */
+int psim_collision_stats(psim_context* ctx, double out[3]);
+
+/* counters of the last step / tree:
+ * [0] particles, [1] reference-equivalent node count 1 + 4 * internal nodes
+ * (quadtree.py:142 num_active_nodes), [2] candidate pairs tested (debug builds of
+ * the sweep only, else 0), [3] contacts resolved, [4] particles removed by
+ * explosions, [5] internal nodes, [6] fixed-point iterations of the contact
+ * solver, [7] dependency rounds of the contact solver */
+int psim_counts(psim_context* ctx, int64_t out[8]);
+
+/* replaces: the per-explosion log lines (particle_system.py:683-689): drains the
+ * queued events; each event = {particle index before removal, affected
+ * neighbours, energy}.  Returns the number written (<= cap) or < 0. */
+typedef struct psim_explosion_event {
+    int32_t particle;
+    int32_t neighbours;
+    double energy;
+} psim_explosion_event;
+int64_t psim_explosion_events(psim_context* ctx, psim_explosion_event* buf, int64_t cap);
+
+/* gravity work counters: runs one counted walk over the current tree and returns
+ * node visits and accepted interactions summed over particles */
+int psim_walk_counts(psim_context* ctx, int64_t out[2]);
+
+/* parity hooks: copy a named internal device array to the host.
+ * psim_debug_size returns the element count (or < 0 for an unknown name);
+ * psim_debug_fetch copies min(bytes, size) bytes.  Names: key perm L owned base
+ * rec node_first node_last node_depth grid_offsets grid_indices cell_key
+ * contact_ij contact_vals delta_temps exploded depth_offsets */
+int64_t psim_debug_size(psim_context* ctx, const char* name);
+int psim_debug_fetch(psim_context* ctx, const char* name, void* dst, size_t bytes);
+
+/* self-test of the device primitives (radix sort, scan, reduction) on n seeded
+ * items against host results; 0 = all matched */
+int psim_selftest(int device_ordinal, int64_t n, uint64_t seed);
+
+/* timing hook for benchmarks: device-side duration in milliseconds of each
+ * stage of the LAST psim_step call (HIP events on the context's stream):
+ * [0] drift+keys, [1] grid build, [2] tree build, [3] gravity walk, [4] kick,
+ * [5] collisions, [6] conduction+cooling, [7] walls+explosions */
+int psim_stage_times(psim_context* ctx, double out_ms[8]);
+
+const char* psim_last_error(void);
+const char* psim_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSIM_H */

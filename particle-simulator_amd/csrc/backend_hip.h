@@ -1,0 +1,460 @@
+// HIP (gfx950 / CDNA4) execution back end: kernel launch of the per-element
+// bodies, and the cooperative primitives the step needs -- LDS-staged LSD radix
+// sort, exclusive scan, ordered f64 reduction.  64-lane wavefronts throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdexcept>
+#include <string>
+#include <stdint.h>
+#include "psim_types.h"
+
+namespace psim {
+namespace be {
+
+inline void check(hipError_t e, const char* what)
+{
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define PSIM_HIP(x) ::psim::be::check((x), #x)
+
+typedef hipStream_t Stream;
+
+inline void* dev_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    PSIM_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    return p;
+}
+inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+inline void dev_memset(Stream st, void* p, int v, size_t bytes) { if (bytes) PSIM_HIP(hipMemsetAsync(p, v, bytes, st)); }
+inline void copy_h2d(Stream st, void* d, const void* h, size_t bytes)
+{
+    if (bytes) PSIM_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));
+}
+inline void copy_d2h(Stream st, void* h, const void* d, size_t bytes)
+{
+    if (bytes) PSIM_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st));
+}
+inline void copy_d2d(Stream st, void* d, const void* s, size_t bytes)
+{
+    if (bytes) PSIM_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, st));
+}
+inline void sync(Stream st) { PSIM_HIP(hipStreamSynchronize(st)); }
+
+// ------------------------------------------------------------------ launch
+template <class F>
+__global__ void __launch_bounds__(256) psim_kernel(int64_t n, F f)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) f(i);
+}
+
+template <class F>
+inline void launch(Stream st, int64_t n, const F& f)
+{
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) throw std::runtime_error("launch: grid too large");
+    hipLaunchKernelGGL(psim_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st, n, f);
+    PSIM_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ block helpers
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over the block's threads (blockDim.x = 64 * nwaves <= 1024);
+// wsum must hold nwaves + 1 words.  Returns exclusive prefix; *total = block sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum, uint32_t* total)
+{
+    int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < nw; ++i) { uint32_t t = wsum[i]; wsum[i] = run; run += t; }
+        wsum[nw] = run;
+    }
+    __syncthreads();
+    uint32_t r = inc - v + wsum[w];
+    *total = wsum[nw];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------ exclusive scan (u32)
+constexpr int kScanItems = 16;
+constexpr int kScanTile = 256 * kScanItems;
+
+__global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* in, uint32_t n, uint32_t* block_sums)
+{
+    __shared__ uint32_t wsum[8];
+    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t s = 0;
+    if (base + kScanItems <= n) {
+        const uint4* p = reinterpret_cast<const uint4*>(in + base);
+#pragma unroll
+        for (int i = 0; i < kScanItems / 4; ++i) { uint4 v = p[i]; s += v.x + v.y + v.z + v.w; }
+    } else {
+        for (int i = 0; i < kScanItems; ++i) if (base + i < n) s += in[base + i];
+    }
+    uint32_t total;
+    (void)block_exclusive_scan(s, wsum, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) scan_spine_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out)
+{
+    __shared__ uint32_t wsum[17];
+    uint32_t per = (nb + 1023) / 1024;
+    uint32_t b0 = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < per; ++i) if (b0 + i < nb) s += block_sums[b0 + i];
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(s, wsum, &total);
+    for (uint32_t i = 0; i < per; ++i)
+        if (b0 + i < nb) { uint32_t t = block_sums[b0 + i]; block_sums[b0 + i] = ex; ex += t; }
+    if (threadIdx.x == 0 && total_out) *total_out = total;
+}
+
+__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
+                                                         const uint32_t* block_sums)
+{
+    __shared__ uint32_t wsum[8];
+    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t s = 0;
+    bool full = base + kScanItems <= n;
+    if (full) {
+        const uint4* p = reinterpret_cast<const uint4*>(in + base);
+#pragma unroll
+        for (int i = 0; i < kScanItems / 4; ++i) {
+            uint4 q = p[i];
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) v[i] = (base + i < n) ? in[base + i] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) s += v[i];
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(s, wsum, &total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) { uint32_t t = v[i]; v[i] = ex; ex += t; }
+    if (full) {
+        uint4* p = reinterpret_cast<uint4*>(out + base);
+#pragma unroll
+        for (int i = 0; i < kScanItems / 4; ++i) p[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) if (base + i < n) out[base + i] = v[i];
+    }
+}
+
+inline size_t scan_temp_words(uint64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile) + 1; }
+
+// out may alias in.  temp: scan_temp_words(n) words.  total_out: device word or null.
+inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* temp,
+                               uint32_t* total_out)
+{
+    if (n == 0) { if (total_out) dev_memset(st, total_out, 0, 4); return; }
+    if (n > 0xfffffff0ull) throw std::runtime_error("exclusive_scan_u32: too many items");
+    uint32_t nb = (uint32_t)((n + kScanTile - 1) / kScanTile);
+    if (nb > 1024u * 64u) throw std::runtime_error("exclusive_scan_u32: spine too long");
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, st, in, (uint32_t)n, temp);
+    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(1024), 0, st, temp, nb, total_out);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, in, out, (uint32_t)n, temp);
+    PSIM_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ radix sort (LSD, 8-bit digits)
+// Per pass: (1) per-tile digit histogram, (2) exclusive scan of the
+// digit-major [256][tiles] table, (3) scatter: each 256-lane workgroup ranks its
+// 2048-key tile stably (wave-level digit matching by ballot + per-wave LDS
+// counters), stages the tile in LDS in sorted order and writes runs of equal
+// digit to their global offsets, so stores are contiguous per digit run.
+constexpr int kSortItems = 8;
+constexpr int kSortTile = 256 * kSortItems;
+
+template <class KeyT>
+__global__ void __launch_bounds__(256) sort_hist_kernel(const KeyT* keys, uint32_t n, int shift, uint32_t ntiles,
+                                                        uint32_t* tile_hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * kSortTile;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t idx = base + k * 256 + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    tile_hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+template <class KeyT>
+__global__ void __launch_bounds__(256) sort_scatter_kernel(const KeyT* kin, const uint32_t* vin, KeyT* kout,
+                                                           uint32_t* vout, uint32_t n, int shift,
+                                                           uint32_t ntiles, const uint32_t* gbase)
+{
+    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t dstart[256];
+    __shared__ uint32_t wsum[8];
+    __shared__ KeyT skey[kSortTile];
+    __shared__ uint32_t sval[kSortTile];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 4 * 256; i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile_base = blockIdx.x * kSortTile;
+    const uint32_t tile_n = (n - tile_base < (uint32_t)kSortTile) ? (n - tile_base) : (uint32_t)kSortTile;
+    KeyT key[kSortItems];
+    uint32_t val[kSortItems];
+    uint32_t rank[kSortItems];
+    const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
+        bool valid = off < tile_n;
+        key[k] = valid ? kin[tile_base + off] : (KeyT)0;
+        val[k] = (valid && vin) ? vin[tile_base + off] : 0u;
+        uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            bool one = (d >> bit) & 1u;
+            uint64_t b = __ballot(one);
+            peers &= one ? b : ~b;
+        }
+        if (!valid) peers = 1ull << lane;
+        uint32_t r = (uint32_t)__popcll(peers & lane_lt);
+        int leader = __ffsll((long long)peers) - 1;
+        uint32_t old = 0;
+        if (valid && lane == leader) {
+            old = cnt[w][d];
+            cnt[w][d] = old + (uint32_t)__popcll(peers);
+        }
+        old = __shfl(old, leader, 64);
+        rank[k] = old + r;
+    }
+    __syncthreads();
+    // per digit: exclusive prefix over the 4 waves, then over digits
+    uint32_t run = 0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) { uint32_t c = cnt[ww][tid]; cnt[ww][tid] = run; run += c; }
+    uint32_t total;
+    uint32_t ds = block_exclusive_scan(run, wsum, &total);
+    dstart[tid] = ds;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
+        if (off < tile_n) {
+            uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+            uint32_t lp = dstart[d] + cnt[w][d] + rank[k];
+            skey[lp] = key[k];
+            sval[lp] = val[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t pos = (uint32_t)(k * 256 + tid);
+        if (pos < tile_n) {
+            KeyT kk = skey[pos];
+            uint32_t d = (uint32_t)(kk >> shift) & 255u;
+            uint32_t g = gbase[d * ntiles + blockIdx.x] + (pos - dstart[d]);
+            kout[g] = kk;
+            if (vout) vout[g] = sval[pos];
+        }
+    }
+}
+
+inline size_t sort_temp_words(uint64_t n)
+{
+    uint64_t ntiles = (n + kSortTile - 1) / kSortTile;
+    return (size_t)(256 * ntiles) + scan_temp_words(256 * ntiles) + 16;
+}
+
+// Sorts (keys[, vals]) by key bits [bit_lo, bit_hi), stable.  k[0]/v[0] hold the
+// input; returns the index (0 or 1) of the buffers holding the result.
+template <class KeyT>
+inline int radix_sort_pairs(Stream st, KeyT* k[2], uint32_t* v[2], uint64_t n, int bit_lo, int bit_hi,
+                            uint32_t* temp)
+{
+    if (n > 0xfffffff0ull) throw std::runtime_error("radix_sort: too many items");
+    int cur = 0;
+    if (n <= 1) return cur;
+    uint32_t ntiles = (uint32_t)((n + kSortTile - 1) / kSortTile);
+    uint32_t* hist = temp;
+    uint32_t* scan_tmp = temp + (size_t)256 * ntiles;
+    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_hist_kernel<KeyT>), dim3(ntiles), dim3(256), 0, st, k[cur],
+                           (uint32_t)n, shift, ntiles, hist);
+        exclusive_scan_u32(st, hist, hist, (uint64_t)256 * ntiles, scan_tmp, nullptr);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_scatter_kernel<KeyT>), dim3(ntiles), dim3(256), 0, st, k[cur],
+                           v ? v[cur] : nullptr, k[cur ^ 1], v ? v[cur ^ 1] : nullptr, (uint32_t)n, shift, ntiles,
+                           hist);
+        PSIM_HIP(hipGetLastError());
+        cur ^= 1;
+    }
+    return cur;
+}
+
+// ------------------------------------------------------------------ ordered f64 reduction
+// Fixed association for a given n (same result every run): 256-lane blocks each
+// sum a contiguous chunk, lanes striding inside it, then one block sums the partials.
+constexpr int kReduceBlocks = 1024;
+
+__global__ void __launch_bounds__(256) reduce_partial_kernel(const double* in, uint64_t n, uint64_t chunk,
+                                                             double* partial)
+{
+    __shared__ double s[256];
+    uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk;
+    if (hi > n) hi = n;
+    double acc = 0.0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) acc += in[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
+}
+
+// temp: kReduceBlocks doubles.  out: device double.
+inline void reduce_sum_f64(Stream st, const double* in, uint64_t n, double* temp, double* out)
+{
+    if (n == 0) { dev_memset(st, out, 0, 8); return; }
+    uint64_t chunk = (n + kReduceBlocks - 1) / kReduceBlocks;
+    chunk = (chunk + 255) / 256 * 256;
+    uint32_t nb = (uint32_t)((n + chunk - 1) / chunk);
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3(nb), dim3(256), 0, st, in, n, chunk, temp);
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3(1), dim3(256), 0, st, (const double*)temp, (uint64_t)nb,
+                       (uint64_t)((nb + 255) / 256 * 256), out);
+    PSIM_HIP(hipGetLastError());
+}
+
+}  // namespace be
+}  // namespace psim
+
+// ------------------------------------------------------------------ wave-cooperative Barnes-Hut walk
+// particle_system.py:69-121 for 64 Morton-adjacent particles at once.  The wave
+// walks the pre-order element array with ONE shared cursor, so every element is
+// fetched once per wave through the scalar path (one 32-byte load, no per-lane
+// gather, no stack).  Each lane keeps the reference's own per-particle
+// decision: a lane that accepts an internal node (w^2 < theta^2 d^2, d^2 > 0)
+// adds its force and parks until the cursor leaves that node's subtree
+// (cursor >= skip); the cursor steps into a node's children while any
+// non-parked lane still needs them.  Per particle the set of interactions is
+// exactly the reference's; only the order of the additions differs.
+namespace psim {
+namespace be {
+
+__device__ __forceinline__ double rsqrt_refined(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-(x * y), y, 1.0);                 // 1 - x y^2
+    return fma(y * e, fma(0.375, e, 0.5), y);         // y (1 + e/2 + 3 e^2 / 8)
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
+    int64_t n, const NodeRec* __restrict__ rec, uint32_t total_elems, const vec2* __restrict__ spos,
+    const double* __restrict__ smass, const uint32_t* __restrict__ perm, const double* __restrict__ inv_mass,
+    vec2* __restrict__ acc_out, const double* __restrict__ w2tab, double theta2, double g_const, double softening,
+    unsigned long long* __restrict__ counters)
+{
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = s < n;
+    double px = 0.0, py = 0.0;
+    if (live) { vec2 p = spos[s]; px = p.x; py = p.y; }
+    uint32_t until = live ? 0u : 0xffffffffu;
+    double ax = 0.0, ay = 0.0;
+    uint32_t visits = 0, inter = 0;
+    uint32_t j = 0;
+    while (j < total_elems) {
+        const uint32_t ju = __builtin_amdgcn_readfirstlane(j);
+        const NodeRec r = rec[ju];
+        const bool leaf = r.depth == kLeaf;
+        const double w2 = leaf ? -1.0 : w2tab[leaf ? 0u : r.depth];
+        const bool active = until <= ju;
+        const double dx = r.x - px, dy = r.y - py;
+        const double d2 = fma(dx, dx, dy * dy);
+        const bool take = active && d2 > 0.0 && w2 < theta2 * d2;
+        if (COUNT) { visits += active ? 1u : 0u; inter += take ? 1u : 0u; }
+        if (__ballot(take) != 0ull) {
+            if (take) {
+                double ri = rsqrt_refined(d2 + softening);
+                double f = r.mass * (ri * ri * ri);
+                ax = fma(f, dx, ax);
+                ay = fma(f, dy, ay);
+                until = r.skip;
+            }
+        }
+        const bool open = active && !take && !leaf;
+        j = (__ballot(open) != 0ull) ? ju + 1u : r.skip;
+    }
+    if (live) {
+        uint32_t p = perm[s];
+        double gm = g_const * smass[s];
+        double im = inv_mass[p];
+        vec2 a;
+        a.x = (gm * ax) * im;
+        a.y = (gm * ay) * im;
+        acc_out[p] = a;
+    }
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)visits);
+        atomicAdd(&counters[1], (unsigned long long)inter);
+    }
+}
+
+}  // namespace be
+}  // namespace psim
+
+// ------------------------------------------------------------------ stage timers (HIP events)
+namespace psim {
+namespace be {
+struct StageTimer {
+    static constexpr int kMarks = 9;
+    hipEvent_t ev[kMarks];
+    bool ready = false, complete = false;
+    void init()
+    {
+        if (ready) return;
+        for (int i = 0; i < kMarks; ++i) PSIM_HIP(hipEventCreate(&ev[i]));
+        ready = true;
+    }
+    void destroy()
+    {
+        if (!ready) return;
+        for (int i = 0; i < kMarks; ++i) (void)hipEventDestroy(ev[i]);
+        ready = false;
+    }
+    void mark(Stream st, int i) { init(); PSIM_HIP(hipEventRecord(ev[i], st)); if (i == kMarks - 1) complete = true; }
+    void read(double* ms)
+    {
+        for (int i = 0; i < kMarks - 1; ++i) ms[i] = 0.0;
+        if (!complete) return;
+        PSIM_HIP(hipEventSynchronize(ev[kMarks - 1]));
+        for (int i = 0; i < kMarks - 1; ++i) {
+            float t = 0.f;
+            PSIM_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            ms[i] = (double)t;
+        }
+    }
+};
+}  // namespace be
+}  // namespace psim

@@ -1,0 +1,397 @@
+// C ABI of libpsim_hip.so (declared in include/psim.h).  Compiled as HIP for
+// gfx950; the test-only host-loop build (tests/hostloop) compiles the same file
+// with -DPSIM_HOSTLOOP and its own back end.
+#if defined(PSIM_HOSTLOOP)
+#include "backend_hostloop.h"
+#else
+#include "backend_hip.h"
+#endif
+#include "psim_sim.h"
+#include "../../include/psim.h"
+
+#include <algorithm>
+#include <random>
+
+static_assert(sizeof(psim_config) == sizeof(psim::Config), "psim_config and psim::Config must match");
+static_assert(sizeof(psim_explosion_event) == sizeof(psim::ExplosionEvent), "event layout");
+
+namespace psim {
+
+void Sim::gravity(vec2* out)
+{
+    if (n == 0) return;
+    uint32_t total = (uint32_t)(n + n_internal);
+    double theta2 = cfg.theta * cfg.theta;          // particle_system.py:88 theta * theta * dist_sq
+#if !defined(PSIM_HOSTLOOP)
+    if (cfg.walk_mode == 0) {
+        int64_t blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(be::gravity_walk_wave_kernel<false>), dim3((unsigned)blocks), dim3(256), 0,
+                           st, n, (const NodeRec*)rec.p, total, (const vec2*)spos.p, (const double*)smass.p,
+                           (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p, out,
+                           (const double*)w2tab.p, theta2, cfg.gravity_constant, cfg.softening,
+                           (unsigned long long*)nullptr);
+        PSIM_HIP(hipGetLastError());
+        return;
+    }
+#endif
+    GravityWalkSimple k;
+    k.n = n; k.rec = rec.p; k.total_elems = total; k.spos = spos.p; k.smass = smass.p; k.perm = perm[sorted_key].p;
+    k.inv_mass = inv_mass.p; k.acc_out = out; k.w2tab = w2tab.p; k.theta2 = theta2; k.g_const = cfg.gravity_constant;
+    k.softening = cfg.softening; k.counters = nullptr;
+    be::launch(st, n, k);
+}
+
+}  // namespace psim
+
+struct psim_context {
+    int device;
+    psim::Sim* sim;
+};
+
+static thread_local std::string g_err;
+
+static void use_device(int device)
+{
+#if !defined(PSIM_HOSTLOOP)
+    PSIM_HIP(hipSetDevice(device));
+#else
+    (void)device;
+#endif
+}
+
+#define PSIM_TRY(ctx_check, ...)                                    \
+    try {                                                           \
+        if (!(ctx_check)) { g_err = "psim: null handle or argument"; return PSIM_ERR_INVALID; } \
+        __VA_ARGS__;                                                \
+        return PSIM_OK;                                             \
+    } catch (const std::invalid_argument& e) {                      \
+        g_err = e.what();                                           \
+        return PSIM_ERR_INVALID;                                    \
+    } catch (const std::exception& e) {                             \
+        g_err = e.what();                                           \
+        return PSIM_ERR_RUNTIME;                                    \
+    }
+
+static psim::Config to_config(const psim_config* c)
+{
+    psim::Config k;
+    memcpy(&k, c, sizeof(k));
+    if (k.solver_iterations < 0) throw std::invalid_argument("psim: solver_iterations < 0");
+    return k;
+}
+
+extern "C" {
+
+const char* psim_last_error(void) { return g_err.c_str(); }
+
+const char* psim_version(void)
+{
+#if defined(PSIM_HOSTLOOP)
+    return "psim 0.1 (host-loop test build, not a product)";
+#else
+    return "psim 0.1 (HIP gfx950)";
+#endif
+}
+
+int psim_create(const psim_config* cfg, int device_ordinal, psim_context** out)
+{
+    PSIM_TRY(cfg && out, {
+        use_device(device_ordinal);
+        psim_context* c = new psim_context;
+        c->device = device_ordinal;
+        c->sim = nullptr;
+        try {
+            c->sim = new psim::Sim(to_config(cfg));
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        *out = c;
+    })
+}
+
+int psim_destroy(psim_context* ctx)
+{
+    PSIM_TRY(ctx, {
+        use_device(ctx->device);
+        delete ctx->sim;
+        delete ctx;
+    })
+}
+
+int psim_set_config(psim_context* ctx, const psim_config* cfg)
+{
+    PSIM_TRY(ctx && cfg, {
+        use_device(ctx->device);
+        ctx->sim->set_config(to_config(cfg));
+    })
+}
+
+int psim_upload(psim_context* ctx, int64_t n, const double* positions, const double* velocities,
+                const double* accelerations, const double* masses, const double* temperatures, const int64_t* radii)
+{
+    PSIM_TRY(ctx && (n == 0 || (positions && masses && temperatures && radii)), {
+        use_device(ctx->device);
+        ctx->sim->upload(n, positions, velocities, accelerations, masses, temperatures, radii);
+    })
+}
+
+int psim_download(psim_context* ctx, double* positions, double* velocities, double* accelerations, double* masses,
+                  double* inverse_masses, double* temperatures, int64_t* radii)
+{
+    PSIM_TRY(ctx, {
+        use_device(ctx->device);
+        ctx->sim->download(positions, velocities, accelerations, masses, inverse_masses, temperatures, radii);
+    })
+}
+
+int64_t psim_num_particles(psim_context* ctx) { return ctx ? ctx->sim->n : -1; }
+
+int psim_prime_gravity(psim_context* ctx)
+{
+    PSIM_TRY(ctx, {
+        use_device(ctx->device);
+        ctx->sim->prime_gravity();
+    })
+}
+
+int psim_step(psim_context* ctx, int64_t k_steps)
+{
+    PSIM_TRY(ctx && k_steps >= 0, {
+        use_device(ctx->device);
+        for (int64_t k = 0; k < k_steps; ++k) ctx->sim->step();
+        psim::be::sync(ctx->sim->st);
+    })
+}
+
+int psim_energies(psim_context* ctx, double out[5])
+{
+    PSIM_TRY(ctx && out, {
+        use_device(ctx->device);
+        ctx->sim->energies(out);
+    })
+}
+
+int psim_collision_stats(psim_context* ctx, double out[3])
+{
+    PSIM_TRY(ctx && out, {
+        out[0] = ctx->sim->coll_totals[0];
+        out[1] = ctx->sim->coll_totals[1];
+        out[2] = ctx->sim->coll_totals[2];
+    })
+}
+
+int psim_counts(psim_context* ctx, int64_t out[8])
+{
+    PSIM_TRY(ctx && out, {
+        psim::Sim* s = ctx->sim;
+        out[0] = s->n;
+        out[1] = s->tree_valid ? (s->n_internal ? 1 + 4 * (int64_t)s->n_internal : (s->tree_n || s->n ? 1 : 0)) : 0;
+        out[2] = s->n_candidates;
+        out[3] = s->n_contacts;
+        out[4] = s->n_exploded;
+        out[5] = s->n_internal;
+        out[6] = s->solver_fixpoint_iters;
+        out[7] = s->solver_rounds;
+    })
+}
+
+int64_t psim_explosion_events(psim_context* ctx, psim_explosion_event* buf, int64_t cap)
+{
+    if (!ctx || (cap > 0 && !buf) || cap < 0) { g_err = "psim: null handle or argument"; return PSIM_ERR_INVALID; }
+    auto& ev = ctx->sim->events;
+    int64_t k = std::min<int64_t>(cap, (int64_t)ev.size());
+    if (k > 0) memcpy(buf, ev.data(), (size_t)k * sizeof(psim_explosion_event));
+    ev.erase(ev.begin(), ev.begin() + k);
+    return k;
+}
+
+static void walk_counts_impl(psim_context* ctx, int64_t out[2])
+{
+    use_device(ctx->device);
+    psim::Sim* s = ctx->sim;
+    out[0] = out[1] = 0;
+    if (!s->tree_valid || s->n == 0) throw std::runtime_error("psim: no tree built yet");
+    uint32_t total = (uint32_t)(s->n + s->n_internal);
+    double theta2 = s->cfg.theta * s->cfg.theta;
+    psim::DevBuf<psim::vec2> scratch;
+    scratch.ensure((size_t)s->n);
+#if !defined(PSIM_HOSTLOOP)
+    psim::DevBuf<unsigned long long> cnt;
+    cnt.ensure(2);
+    psim::be::dev_memset(s->st, cnt.p, 0, 16);
+    int64_t blocks = (s->n + 255) / 256;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(psim::be::gravity_walk_wave_kernel<true>), dim3((unsigned)blocks), dim3(256), 0,
+                       s->st, s->n, (const psim::NodeRec*)s->rec.p, total, (const psim::vec2*)s->spos.p,
+                       (const double*)s->smass.p, (const uint32_t*)s->perm[s->sorted_key].p,
+                       (const double*)s->inv_mass.p, scratch.p, (const double*)s->w2tab.p, theta2,
+                       s->cfg.gravity_constant, s->cfg.softening, cnt.p);
+    PSIM_HIP(hipGetLastError());
+    unsigned long long h[2];
+    psim::be::copy_d2h(s->st, h, cnt.p, 16);
+    psim::be::sync(s->st);
+    out[0] = (int64_t)h[0];
+    out[1] = (int64_t)h[1];
+#else
+    psim::DevBuf<uint32_t> cnt;
+    cnt.ensure(2);
+    psim::be::dev_memset(s->st, cnt.p, 0, 8);
+    psim::GravityWalkSimple k;
+    k.n = s->n; k.rec = s->rec.p; k.total_elems = total; k.spos = s->spos.p; k.smass = s->smass.p;
+    k.perm = s->perm[s->sorted_key].p; k.inv_mass = s->inv_mass.p; k.acc_out = scratch.p; k.w2tab = s->w2tab.p;
+    k.theta2 = theta2; k.g_const = s->cfg.gravity_constant; k.softening = s->cfg.softening; k.counters = cnt.p;
+    psim::be::launch(s->st, s->n, k);
+    out[0] = cnt.p[0];
+    out[1] = cnt.p[1];
+#endif
+}
+
+int psim_walk_counts(psim_context* ctx, int64_t out[2])
+{
+    PSIM_TRY(ctx && out, walk_counts_impl(ctx, out))
+}
+
+int psim_stage_times(psim_context* ctx, double out_ms[8])
+{
+    PSIM_TRY(ctx && out_ms, {
+        use_device(ctx->device);
+        ctx->sim->timer.read(out_ms);
+    })
+}
+
+// ---- debug access
+struct DebugArray {
+    const void* ptr;
+    int64_t count;
+    size_t elem;
+};
+
+static bool find_debug_array(psim::Sim* s, const std::string& name, DebugArray* a)
+{
+    int64_t n = s->tree_n ? s->tree_n : s->n;
+    int64_t cells = (int64_t)s->cfg.grid_w * s->cfg.grid_h;
+    if (name == "key") *a = {s->key[s->sorted_key].p, n, 8};
+    else if (name == "perm") *a = {s->perm[s->sorted_key].p, n, 4};
+    else if (name == "L") *a = {s->L.p, n, 1};
+    else if (name == "owned") *a = {s->owned.p, n, 4};
+    else if (name == "base") *a = {s->base.p, n, 4};
+    else if (name == "rec") *a = {s->rec.p, n + s->n_internal, sizeof(psim::NodeRec)};
+    else if (name == "node_first") *a = {s->node_first.p, s->n_internal, 4};
+    else if (name == "node_last") *a = {s->node_last.p, s->n_internal, 4};
+    else if (name == "node_depth") *a = {s->node_depth[0].p, s->n_internal, 4};
+    else if (name == "depth_offsets") *a = {s->depth_off.p, psim::kKeyLevels + 2, 4};
+    else if (name == "grid_offsets") *a = {s->offsets.p, cells + 1, 4};
+    else if (name == "grid_indices") *a = {s->cperm[s->sorted_ckey].p, n, 4};
+    else if (name == "cell_key") *a = {s->ckey[s->sorted_ckey].p, n, 4};
+    else if (name == "contact_ij") *a = {s->log_ij.p, s->log_n, 8};
+    else if (name == "contact_vals") *a = {s->log_vals.p, s->log_n, 24};
+    else if (name == "delta_temps") *a = {s->delta_dbg.p, s->delta_dbg.p ? n : 0, 8};
+    else if (name == "exploded") *a = {nullptr, (int64_t)s->last_exploded.size(), 4};
+    else return false;
+    return true;
+}
+
+int64_t psim_debug_size(psim_context* ctx, const char* name)
+{
+    if (!ctx || !name) { g_err = "psim: null handle or argument"; return PSIM_ERR_INVALID; }
+    DebugArray a;
+    if (!find_debug_array(ctx->sim, name, &a)) { g_err = std::string("psim: unknown debug array ") + name; return PSIM_ERR_INVALID; }
+    return a.count;
+}
+
+int psim_debug_fetch(psim_context* ctx, const char* name, void* dst, size_t bytes)
+{
+    PSIM_TRY(ctx && name && (dst || bytes == 0), {
+        use_device(ctx->device);
+        DebugArray a;
+        if (!find_debug_array(ctx->sim, name, &a)) throw std::invalid_argument(std::string("psim: unknown debug array ") + name);
+        size_t have = (size_t)a.count * a.elem;
+        size_t k = std::min(bytes, have);
+        if (std::string(name) == "exploded") {
+            if (k) memcpy(dst, ctx->sim->last_exploded.data(), k);
+        } else if (k) {
+            psim::be::copy_d2h(ctx->sim->st, dst, a.ptr, k);
+            psim::be::sync(ctx->sim->st);
+        }
+    })
+}
+
+// ---- primitive self-test
+int psim_selftest(int device_ordinal, int64_t n, uint64_t seed)
+{
+    PSIM_TRY(n >= 0 && n < (1ll << 31), {
+        use_device(device_ordinal);
+        using namespace psim;
+        be::Stream st = 0;
+        std::mt19937_64 rng(seed);
+        size_t c = (size_t)n;
+        // --- u64 sort with payload, all 64 bits, duplicates forced
+        std::vector<uint64_t> hk(c);
+        std::vector<uint32_t> hv(c);
+        for (size_t i = 0; i < c; ++i) { hk[i] = rng(); if (i % 7 == 3 && i) hk[i] = hk[i - 1]; hv[i] = (uint32_t)i; }
+        DevBuf<uint64_t> k0, k1;
+        DevBuf<uint32_t> v0, v1, tmp, stmp;
+        k0.ensure(c); k1.ensure(c); v0.ensure(c); v1.ensure(c); tmp.ensure(be::sort_temp_words(c));
+        be::copy_h2d(st, k0.p, hk.data(), c * 8);
+        be::copy_h2d(st, v0.p, hv.data(), c * 4);
+        uint64_t* kk[2] = {k0.p, k1.p};
+        uint32_t* vv[2] = {v0.p, v1.p};
+        int r = be::radix_sort_pairs<uint64_t>(st, kk, vv, (uint64_t)n, 0, 64, tmp.p);
+        std::vector<uint64_t> gk(c);
+        std::vector<uint32_t> gv(c);
+        be::copy_d2h(st, gk.data(), kk[r], c * 8);
+        be::copy_d2h(st, gv.data(), vv[r], c * 4);
+        be::sync(st);
+        std::vector<uint32_t> order(c);
+        for (size_t i = 0; i < c; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hk[a] < hk[b]; });
+        for (size_t i = 0; i < c; ++i)
+            if (gk[i] != hk[order[i]] || gv[i] != order[i]) throw std::runtime_error("selftest: u64 sort mismatch at " + std::to_string(i));
+        // --- u32 sort on a bit sub-range [0, 20)
+        std::vector<uint32_t> h32(c);
+        for (size_t i = 0; i < c; ++i) h32[i] = (uint32_t)rng() & 0xfffffu;
+        DevBuf<uint32_t> a0, a1;
+        a0.ensure(c); a1.ensure(c);
+        be::copy_h2d(st, a0.p, h32.data(), c * 4);
+        be::copy_h2d(st, v0.p, hv.data(), c * 4);
+        uint32_t* ak[2] = {a0.p, a1.p};
+        r = be::radix_sort_pairs<uint32_t>(st, ak, vv, (uint64_t)n, 0, 20, tmp.p);
+        std::vector<uint32_t> g32(c);
+        be::copy_d2h(st, g32.data(), ak[r], c * 4);
+        be::copy_d2h(st, gv.data(), vv[r], c * 4);
+        be::sync(st);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return a < b; });
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h32[a] < h32[b]; });
+        for (size_t i = 0; i < c; ++i)
+            if (g32[i] != h32[order[i]] || gv[i] != order[i]) throw std::runtime_error("selftest: u32 sort mismatch at " + std::to_string(i));
+        // --- exclusive scan
+        std::vector<uint32_t> hs(c), gs(c);
+        for (size_t i = 0; i < c; ++i) hs[i] = (uint32_t)(rng() % 5);
+        stmp.ensure(be::scan_temp_words(c));
+        DevBuf<uint32_t> tot;
+        tot.ensure(1);
+        be::copy_h2d(st, a0.p, hs.data(), c * 4);
+        be::exclusive_scan_u32(st, a0.p, a1.p, (uint64_t)n, stmp.p, tot.p);
+        uint32_t gtot = 0;
+        be::copy_d2h(st, gs.data(), a1.p, c * 4);
+        be::copy_d2h(st, &gtot, tot.p, 4);
+        be::sync(st);
+        uint32_t run = 0;
+        for (size_t i = 0; i < c; ++i) { if (gs[i] != run) throw std::runtime_error("selftest: scan mismatch at " + std::to_string(i)); run += hs[i]; }
+        if (gtot != run) throw std::runtime_error("selftest: scan total mismatch");
+        // --- reduction (integers stored as doubles: exact in any order)
+        std::vector<double> hd(c);
+        double want = 0.0;
+        for (size_t i = 0; i < c; ++i) { hd[i] = (double)(rng() % 1000); want += hd[i]; }
+        DevBuf<double> d0, dt, dout;
+        d0.ensure(c); dt.ensure(be::kReduceBlocks); dout.ensure(1);
+        be::copy_h2d(st, d0.p, hd.data(), c * 8);
+        be::reduce_sum_f64(st, d0.p, (uint64_t)n, dt.p, dout.p);
+        double got = -1.0;
+        be::copy_d2h(st, &got, dout.p, 8);
+        be::sync(st);
+        if (got != want) throw std::runtime_error("selftest: reduction mismatch");
+    })
+}
+
+}  // extern "C"

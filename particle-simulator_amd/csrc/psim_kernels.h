@@ -1,0 +1,1107 @@
+// Per-element kernel bodies of the physics step.
+//
+// Every struct below is the body of one data-parallel kernel: operator()(i) is
+// the work of element i.  backend_hip.h runs them as HIP kernels (one lane per
+// element); the test-only host-loop build runs the same bodies in a for loop so
+// the step's logic can be checked on a machine without a GPU.
+//
+// Reference citations are file:line into NeoLorenzo/Particle-Simulator.
+// The library is compiled with -ffp-contract=off: wherever the reference stage
+// is strict IEEE FP64 the expression order below IS the contract.
+#pragma once
+#include <math.h>
+#include "psim_types.h"
+
+namespace psim {
+
+// --------------------------------------------------------------- helpers
+#if defined(PSIM_HOSTLOOP)
+inline uint32_t atomic_inc_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+inline int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
+#else
+__device__ __forceinline__ uint32_t atomic_inc_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ int clz64(uint64_t x) { return x ? __clzll((long long)x) : 64; }
+#endif
+
+// quadtree.py:13-19 (_get_quadrant) + :24-38,62-63 (child boxes, centre = x + w/2):
+// descend 32 levels from the root box exactly as an insertion would, recording
+// quadrant = 2*(y >= cy) + (x >= cx) per level, most significant first.
+// Coordinates outside the box keep comparing against centres, so keys saturate.
+PSIM_HD PSIM_FORCEINLINE uint64_t morton_key(double x, double y, double W, double H)
+{
+    double x0 = 0.0, y0 = 0.0, w = W, h = H;
+    uint64_t key = 0;
+    for (int l = 0; l < kKeyLevels; ++l) {
+        double hw = w / 2, hh = h / 2;
+        double cx = x0 + hw, cy = y0 + hh;
+        uint64_t bx = (x < cx) ? 0u : 1u;
+        uint64_t by = (y < cy) ? 0u : 1u;
+        key = (key << 2) | (by << 1) | bx;
+        if (bx) x0 = cx;
+        if (by) y0 = cy;
+        w = hw;
+        h = hh;
+    }
+    return key;
+}
+
+// particle_system.py:744-748: (x / cell_size).astype(int32) then clip.  The
+// x86 conversion numpy uses yields INT32_MIN for NaN and out-of-range values.
+PSIM_HD PSIM_FORCEINLINE int32_t cell_coord(double v, double cell_size, int32_t g)
+{
+    double q = v / cell_size;
+    int32_t c;
+    if (!(q > -2147483649.0 && q < 2147483648.0)) c = INT32_MIN;
+    else c = (int32_t)q;
+    if (c < 0) c = 0;
+    if (c > g - 1) c = g - 1;
+    return c;
+}
+
+PSIM_HD PSIM_FORCEINLINE int shared_levels(uint64_t a, uint64_t b)
+{
+    int s = clz64(a ^ b) >> 1;          // identical keys: 32
+    return s > kMaxInternalDepth ? kMaxInternalDepth : s;
+}
+
+// --------------------------------------------------------------- stage 1/2: drift, keys
+// particle_system.py:528 (drift, dt = 1) fused with the Morton key (quadtree
+// insertion path) and the grid cell id (particle_system.py:744-749).
+struct DriftKeys {
+    int64_t n;
+    vec2* pos;
+    const vec2* vel;
+    const vec2* acc;
+    uint64_t* key;
+    uint32_t* perm;
+    uint32_t* ckey;
+    uint32_t* cperm;
+    double W, H, cell_size;
+    int32_t gw, gh;
+    int32_t do_drift;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        vec2 p = pos[i];
+        if (do_drift) {
+            vec2 v = vel[i], a = acc[i];
+            p.x = p.x + (v.x + 0.5 * a.x);
+            p.y = p.y + (v.y + 0.5 * a.y);
+            pos[i] = p;
+        }
+        key[i] = morton_key(p.x, p.y, W, H);
+        perm[i] = (uint32_t)i;
+        int32_t cx = cell_coord(p.x, cell_size, gw);
+        int32_t cy = cell_coord(p.y, cell_size, gh);
+        ckey[i] = (uint32_t)(cy * gw + cx);
+        cperm[i] = (uint32_t)i;
+    }
+};
+
+// CSR offsets of a sorted u32 key array: offsets[c] = first k with keys[k] >= c
+// (particle_system.py:752-755 bincount + cumsum, without the histogram).
+// Run over n + 1 elements.
+struct SegmentOffsets {
+    int64_t n;
+    const uint32_t* keys;
+    int32_t* offsets;
+    uint32_t num_segments;
+    PSIM_HD void operator()(int64_t k) const
+    {
+        int64_t lo = (k == 0) ? 0 : (int64_t)keys[k - 1] + 1;
+        int64_t hi = (k == n) ? (int64_t)num_segments : (int64_t)keys[k];
+        for (int64_t c = lo; c <= hi; ++c) offsets[c] = (int32_t)k;
+    }
+};
+
+// cell-sorted ("slot space") copies used by the neighbour sweeps
+struct GatherCell {
+    int64_t n;
+    const uint32_t* cperm;
+    const vec2* pos;
+    const int32_t* radii;
+    vec2* cpos;
+    int32_t* crad;
+    PSIM_HD void operator()(int64_t k) const
+    {
+        uint32_t p = cperm[k];
+        cpos[k] = pos[p];
+        crad[k] = radii[p];
+    }
+};
+
+// --------------------------------------------------------------- stage 3: linear quadtree
+struct GatherTree {
+    int64_t n;
+    const uint32_t* perm;
+    const vec2* pos;
+    const double* mass;
+    vec2* spos;
+    double* smass;
+    PSIM_HD void operator()(int64_t s) const
+    {
+        uint32_t p = perm[s];
+        spos[s] = pos[p];
+        smass[s] = mass[p];
+    }
+};
+
+// For sorted particle s: L[s] = number of leading levels its key shares with
+// key[s+1] (capped at 31; -1 for the last particle).  The reference's internal
+// nodes (quadtree.py:54-59: a leaf that receives a second particle subdivides)
+// are exactly the (depth, prefix) cells holding >= 2 particles; the cell of
+// depth d whose first particle is s exists iff L[s] >= d, and s is its first
+// particle iff L[s-1] < d.  So s "owns" the internal nodes of depths
+// L[s-1]+1 .. L[s], a chain, and numbering nodes by (s, depth) is a pre-order.
+struct TreeLinks {
+    int64_t n;
+    const uint64_t* key;
+    int8_t* L;
+    uint32_t* owned;
+    PSIM_HD void operator()(int64_t s) const
+    {
+        int l = (s + 1 < n) ? shared_levels(key[s], key[s + 1]) : -1;
+        int lp = (s > 0) ? shared_levels(key[s - 1], key[s]) : -1;
+        L[s] = (int8_t)l;
+        owned[s] = (uint32_t)(l > lp ? l - lp : 0);
+    }
+};
+
+PSIM_HD PSIM_FORCEINLINE uint32_t range_last(const uint64_t* key, uint32_t s, uint32_t n, int d)
+{
+    if (d == 0) return n - 1;
+    int sh = 64 - 2 * d;
+    uint64_t pre = key[s] >> sh;
+    uint32_t lo = s, hi;
+    uint32_t step = 1;
+    for (;;) {
+        uint64_t t = (uint64_t)lo + step;
+        if (t >= n) { hi = n; break; }
+        if ((key[t] >> sh) != pre) { hi = (uint32_t)t; break; }
+        lo = (uint32_t)t;
+        step <<= 1;
+    }
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if ((key[mid] >> sh) == pre) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Writes the pre-order element array: for sorted particle s its owned internal
+// nodes (shallowest first) followed by its own leaf.  Internal node ids are
+// base[s] + k; the element of node id owned by s sits at index s + id.
+struct TreeEmit {
+    int64_t n;
+    const uint64_t* key;
+    const int8_t* L;
+    const uint32_t* owned;
+    const uint32_t* base;      // exclusive scan of owned
+    const vec2* spos;
+    const double* smass;
+    uint32_t total_elems;      // n + number of internal nodes
+    NodeRec* rec;
+    uint32_t* node_first;
+    uint32_t* node_last;
+    uint32_t* node_depth;      // u32 so it can be a radix-sort key
+    uint32_t* node_id;
+    PSIM_HD void operator()(int64_t s) const
+    {
+        uint32_t b = base[s], own = owned[s];
+        int lp = (s > 0) ? (int)L[s - 1] : -1;
+        for (uint32_t k = 0; k < own; ++k) {
+            int d = lp + 1 + (int)k;
+            uint32_t id = b + k;
+            uint32_t e = range_last(key, (uint32_t)s, (uint32_t)n, d);
+            uint32_t skip = (e + 1 < (uint32_t)n) ? (e + 1) + base[e + 1] : total_elems;
+            NodeRec r;
+            r.mass = 0.0; r.x = 0.0; r.y = 0.0;
+            r.skip = skip;
+            r.depth = (uint32_t)d;
+            rec[(uint32_t)s + id] = r;
+            node_first[id] = (uint32_t)s;
+            node_last[id] = e;
+            node_depth[id] = (uint32_t)d;
+            node_id[id] = id;
+        }
+        uint32_t le = (uint32_t)s + b + own;
+        NodeRec r;
+        r.mass = smass[s];
+        r.x = spos[s].x;
+        r.y = spos[s].y;
+        r.skip = le + 1;
+        r.depth = kLeaf;
+        rec[le] = r;
+    }
+};
+
+// quadtree.py:85-114 (_calculate_mass_distribution_jit) for the internal nodes
+// of one depth, children visited in quadrant order 0..3, strict FP64:
+//   total += m_c; num += com_c * m_c (mass <= 0 skipped); com = num / total.
+// Also accumulates this node's sibling-pair potential energy
+// (particle_system.py:43-63) while the four children are in registers.
+struct TreeCom {
+    int64_t count;
+    const uint32_t* ids;       // node ids of this depth
+    int depth;
+    int64_t n;
+    const uint64_t* key;
+    const int8_t* L;
+    const uint32_t* base;
+    const vec2* spos;
+    const double* smass;
+    const uint32_t* node_first;
+    const uint32_t* node_last;
+    NodeRec* rec;
+    double* pe_node;
+    double g_const, softening;
+    PSIM_HD void operator()(int64_t t) const
+    {
+        uint32_t id = ids[t];
+        uint32_t s = node_first[id], e = node_last[id];
+        int sh = 62 - 2 * depth;
+        // quadrant boundaries inside [s, e]
+        uint32_t bnd[5];
+        bnd[0] = s;
+        bnd[4] = e + 1;
+        for (int q = 1; q < 4; ++q) {
+            uint32_t lo = bnd[q - 1], hi = e + 1;     // first index with digit >= q
+            while (lo < hi) {
+                uint32_t mid = lo + (hi - lo) / 2;
+                if (((key[mid] >> sh) & 3u) >= (uint64_t)q) hi = mid; else lo = mid + 1;
+            }
+            bnd[q] = lo;
+        }
+        double cm[4], cx[4], cy[4];
+        for (int q = 0; q < 4; ++q) {
+            uint32_t c0 = bnd[q], cnt = bnd[q + 1] - bnd[q];
+            cm[q] = 0.0; cx[q] = 0.0; cy[q] = 0.0;
+            if (cnt == 1) {
+                cm[q] = smass[c0]; cx[q] = spos[c0].x; cy[q] = spos[c0].y;
+            } else if (cnt >= 2) {
+                if (depth + 1 <= kMaxInternalDepth) {
+                    int lp = (c0 > 0) ? (int)L[c0 - 1] : -1;
+                    uint32_t cid = base[c0] + (uint32_t)(depth - lp);
+                    const NodeRec& r = rec[c0 + cid];
+                    cm[q] = r.mass; cx[q] = r.x; cy[q] = r.y;
+                } else {
+                    // bucket leaf: particles that coincide to all 32 levels (the
+                    // reference never terminates on these); fold them in order
+                    double tm = 0.0, nx = 0.0, ny = 0.0;
+                    for (uint32_t k = c0; k < c0 + cnt; ++k) {
+                        double m = smass[k];
+                        if (m > 0) { tm += m; nx += spos[k].x * m; ny += spos[k].y * m; }
+                    }
+                    cm[q] = tm;
+                    if (tm > 0) { cx[q] = nx / tm; cy[q] = ny / tm; }
+                }
+            }
+        }
+        double total = 0.0, nx = 0.0, ny = 0.0;
+        for (int q = 0; q < 4; ++q) {
+            if (cm[q] > 0) {
+                total += cm[q];
+                nx += cx[q] * cm[q];
+                ny += cy[q] * cm[q];
+            }
+        }
+        NodeRec& out = rec[s + id];
+        out.mass = total;
+        if (total > 0) { out.x = nx / total; out.y = ny / total; }
+        double pe = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            if (!(cm[i] > 0)) continue;
+            for (int j = i + 1; j < 4; ++j) {
+                if (!(cm[j] > 0)) continue;
+                double dx = cx[j] - cx[i], dy = cy[j] - cy[i];
+                double d2 = dx * dx + dy * dy;
+                if (d2 > 0) pe -= (g_const * cm[i] * cm[j]) / sqrt(d2 + softening);
+            }
+        }
+        pe_node[id] = pe;
+    }
+};
+
+// --------------------------------------------------------------- stage 4: gravity
+// particle_system.py:69-121 (_traverse_tree_jit) as a stackless pre-order walk:
+// an internal node is accepted iff d2 > 0 and w*w < theta*theta*d2, otherwise
+// the walk steps into its first child (the next element); a leaf interacts iff
+// d2 > 0 (which also excludes the particle itself, :105).  Accepted or leaf:
+// continue at rec.skip.  One element per sorted particle; this is the plain
+// one-lane-per-particle form (the wave-cooperative kernel lives in backend_hip.h).
+PSIM_HD PSIM_FORCEINLINE double inv_cube_soft(double x)
+{
+    double r = 1.0 / sqrt(x);
+    return r * r * r;
+}
+
+struct GravityWalkSimple {
+    int64_t n;
+    const NodeRec* rec;
+    uint32_t total_elems;
+    const vec2* spos;
+    const double* smass;
+    const uint32_t* perm;
+    const double* inv_mass;     // index space
+    vec2* acc_out;              // index space
+    const double* w2tab;        // [32] squared node width per depth
+    double theta2, g_const, softening;
+    uint32_t* counters;         // optional [2]: visits, interactions
+    PSIM_HD void operator()(int64_t s) const
+    {
+        double px = spos[s].x, py = spos[s].y;
+        double ax = 0.0, ay = 0.0;
+        uint32_t j = 0, visits = 0, inter = 0;
+        while (j < total_elems) {
+            NodeRec r = rec[j];
+            double dx = r.x - px, dy = r.y - py;
+            double d2 = dx * dx + dy * dy;
+            double w2 = (r.depth == kLeaf) ? -1.0 : w2tab[r.depth];
+            ++visits;
+            if (d2 > 0 && w2 < theta2 * d2) {
+                double f = r.mass * inv_cube_soft(d2 + softening);
+                ax += f * dx;
+                ay += f * dy;
+                ++inter;
+                j = r.skip;
+            } else {
+                j = j + 1;
+            }
+        }
+        uint32_t p = perm[s];
+        double gm = g_const * smass[s];
+        double im = inv_mass[p];
+        vec2 a;
+        a.x = (gm * ax) * im;      // particle_system.py:25  a = F * (1/m)
+        a.y = (gm * ay) * im;
+        acc_out[p] = a;
+        if (counters) {
+            atomic_inc_u32(&counters[0], visits);
+            atomic_inc_u32(&counters[1], inter);
+        }
+    }
+};
+
+// particle_system.py:540  v += 0.5 * (a_old + a_new)
+struct Kick {
+    int64_t n;
+    vec2* vel;
+    const vec2* acc_old;
+    const vec2* acc_new;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        vec2 v = vel[i], a = acc_old[i], b = acc_new[i];
+        v.x = v.x + 0.5 * (a.x + b.x);
+        v.y = v.y + 0.5 * (a.y + b.y);
+        vel[i] = v;
+    }
+};
+
+// --------------------------------------------------------------- stage 6: collisions
+// Candidate order of one sweep (particle_system.py:148-197): home cells in
+// row-major order; inside a home cell first the in-cell pairs (a < b in grid
+// order), then the 8 neighbour cells in (dy, dx) order, p1 over the home cell
+// (outer), p2 over the neighbour (inner), visited iff index(p1) < index(p2).
+// pair_key packs that order into one integer; a pair is always keyed from its
+// lower-index particle, whose cell is the home cell.
+struct GridView {
+    const uint32_t* cperm;     // slot -> particle index (grid_indices)
+    const uint32_t* ckey;      // slot -> cell
+    const int32_t* offsets;    // cell -> first slot
+    int32_t gw, gh;
+};
+
+PSIM_HD PSIM_FORCEINLINE uint64_t make_pair_key(uint32_t cell, uint32_t phase, uint32_t a, uint32_t b)
+{
+    return ((uint64_t)cell << 40) | ((uint64_t)phase << 36) | ((uint64_t)a << kSlotBits) | (uint64_t)b;
+}
+
+PSIM_HD PSIM_FORCEINLINE uint32_t neighbour_phase(int dy, int dx) { return 1u + (uint32_t)((dy + 1) * 3 + (dx + 1)); }
+
+PSIM_HD PSIM_FORCEINLINE uint64_t pair_key(const GridView& g, uint32_t sx, uint32_t sy)
+{
+    uint32_t lo = sx, hi = sy;
+    if (g.cperm[sy] < g.cperm[sx]) { lo = sy; hi = sx; }
+    uint32_t cl = g.ckey[lo], ch = g.ckey[hi];
+    uint32_t a = lo - (uint32_t)g.offsets[cl], b = hi - (uint32_t)g.offsets[ch];
+    uint32_t phase = 0;
+    if (cl != ch) {
+        int dx = (int)(ch % (uint32_t)g.gw) - (int)(cl % (uint32_t)g.gw);
+        int dy = (int)(ch / (uint32_t)g.gw) - (int)(cl / (uint32_t)g.gw);
+        phase = neighbour_phase(dy, dx);
+    }
+    return make_pair_key(cl, phase, a, b);
+}
+
+PSIM_HD PSIM_FORCEINLINE void decode_pair_key(const GridView& g, uint64_t key, uint32_t* si, uint32_t* sj)
+{
+    uint32_t cell = (uint32_t)(key >> 40);
+    uint32_t phase = (uint32_t)(key >> 36) & 15u;
+    uint32_t a = (uint32_t)(key >> kSlotBits) & kSlotMask, b = (uint32_t)key & kSlotMask;
+    uint32_t nc = cell;
+    if (phase) {
+        int idx = (int)phase - 1;
+        nc = (uint32_t)((int)cell + (idx / 3 - 1) * g.gw + (idx % 3 - 1));
+    }
+    *si = (uint32_t)g.offsets[cell] + a;
+    *sj = (uint32_t)g.offsets[nc] + b;
+}
+
+// contact test of particle_system.py:210-217 (strict): 0 < d2 < (ri + rj)^2
+PSIM_HD PSIM_FORCEINLINE bool in_contact(vec2 pi, vec2 pj, int32_t ri, int32_t rj)
+{
+    double dx = pj.x - pi.x, dy = pj.y - pi.y;
+    double d2 = dx * dx + dy * dy;
+    int64_t md = (int64_t)ri + (int64_t)rj;
+    return d2 < (double)(md * md) && d2 > 0;
+}
+
+// Enumerate, for slot k, every slot y of the 3x3 cell neighbourhood (own cell
+// first, then neighbours in (dy, dx) order).  F(y, phase_from_k_to_y).
+template <class F>
+PSIM_HD PSIM_FORCEINLINE void for_each_neighbour_slot(const GridView& g, uint32_t k, F f)
+{
+    uint32_t c = g.ckey[k];
+    int cx = (int)(c % (uint32_t)g.gw), cy = (int)(c / (uint32_t)g.gw);
+    for (int32_t b = g.offsets[c]; b < g.offsets[c + 1]; ++b)
+        if ((uint32_t)b != k) f((uint32_t)b);
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            int nx = cx + dx, ny = cy + dy;
+            if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) continue;
+            uint32_t nc = (uint32_t)(ny * g.gw + nx);
+            for (int32_t b = g.offsets[nc]; b < g.offsets[nc + 1]; ++b) f((uint32_t)b);
+        }
+}
+
+// Sweep 0: test every candidate pair against the sweep's initial positions and
+// append the keys of those in contact (unordered; sorted afterwards).
+struct ContactDetect {
+    int64_t n;
+    GridView g;
+    const vec2* cpos;
+    const int32_t* crad;
+    uint64_t* out_keys;
+    uint32_t* counter;
+    uint32_t cap;
+    uint32_t* cand_counter;    // optional: number of candidate pairs
+    PSIM_HD void operator()(int64_t kk) const
+    {
+        uint32_t k = (uint32_t)kk;
+        uint32_t p = g.cperm[k];
+        uint32_t c = g.ckey[k];
+        uint32_t a = k - (uint32_t)g.offsets[c];
+        vec2 P = cpos[k];
+        int32_t rp = crad[k];
+        int cx = (int)(c % (uint32_t)g.gw), cy = (int)(c / (uint32_t)g.gw);
+        uint32_t ncand = 0;
+        for (int32_t b = (int32_t)k + 1; b < g.offsets[c + 1]; ++b) {
+            ++ncand;
+            if (in_contact(P, cpos[b], rp, crad[b])) {
+                uint32_t at = atomic_inc_u32(counter, 1);
+                if (at < cap) out_keys[at] = make_pair_key(c, 0, a, (uint32_t)b - (uint32_t)g.offsets[c]);
+            }
+        }
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dx == 0 && dy == 0) continue;
+                int nx = cx + dx, ny = cy + dy;
+                if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) continue;
+                uint32_t nc = (uint32_t)(ny * g.gw + nx);
+                int32_t o = g.offsets[nc];
+                for (int32_t b = o; b < g.offsets[nc + 1]; ++b) {
+                    if (g.cperm[b] > p) {
+                        ++ncand;
+                        if (in_contact(P, cpos[b], rp, crad[b])) {
+                            uint32_t at = atomic_inc_u32(counter, 1);
+                            if (at < cap)
+                                out_keys[at] = make_pair_key(c, neighbour_phase(dy, dx), a, (uint32_t)(b - o));
+                        }
+                    }
+                }
+            }
+        if (cand_counter && ncand) atomic_inc_u32(cand_counter, ncand);
+    }
+};
+
+// hypothesised contact h -> its two slots, plus two adjacency entries
+// (slot << 32 | h) that are then sorted to give each slot its contacts in order.
+struct ContactDecode {
+    int64_t n;
+    GridView g;
+    const uint64_t* hkeys;
+    uint32_t* hsi;
+    uint32_t* hsj;
+    uint64_t* adj;
+    uint32_t* done;
+    PSIM_HD void operator()(int64_t h) const
+    {
+        uint32_t si, sj;
+        decode_pair_key(g, hkeys[h], &si, &sj);
+        hsi[h] = si;
+        hsj[h] = sj;
+        adj[2 * h] = ((uint64_t)si << 32) | (uint64_t)h;
+        adj[2 * h + 1] = ((uint64_t)sj << 32) | (uint64_t)h;
+        done[h] = 0;
+    }
+};
+
+// over sorted adjacency entries: segment starts per slot and, for each contact
+// and side, the previous contact of the same slot (-1: none).
+struct AdjLinks {
+    int64_t n;
+    const uint64_t* adj;
+    const uint32_t* hsi;
+    int32_t* cseg;       // slot -> first adjacency entry (-1 = clean)
+    int32_t* prev;       // [2h + side]
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t slot = (uint32_t)(adj[e] >> 32), h = (uint32_t)adj[e];
+        bool first = (e == 0) || ((uint32_t)(adj[e - 1] >> 32) != slot);
+        if (first) cseg[slot] = (int32_t)e;
+        int side = (hsi[h] == slot) ? 0 : 1;
+        prev[2 * h + side] = first ? -1 : (int32_t)(uint32_t)adj[e - 1];
+    }
+};
+
+// particle_system.py:200-268 (_resolve_collision_jit), strict FP64, on copies
+// of the two bodies (i = lower particle index).  Returns whether they touched.
+PSIM_HD PSIM_FORCEINLINE bool resolve_pair(BodyState& I, BodyState& J, double mi, double mj, int32_t ri,
+                                           int32_t rj, double G, double soft, double restitution,
+                                           double pos_correct, double* vals)
+{
+    int64_t min_dist = (int64_t)ri + (int64_t)rj;
+    double dvx = J.pos.x - I.pos.x, dvy = J.pos.y - I.pos.y;
+    double d2 = dvx * dvx + dvy * dvy;
+    vals[0] = 0.0; vals[1] = 0.0; vals[2] = 0.0;
+    if (!(d2 < (double)(min_dist * min_dist) && d2 > 0)) return false;
+    double dist = sqrt(d2);
+    double M = mi + mj;
+    double vib0 = I.vel.x, vib1 = I.vel.y, vjb0 = J.vel.x, vjb1 = J.vel.y;
+    double ke_before = 0.5 * mi * (vib0 * vib0 + vib1 * vib1) + 0.5 * mj * (vjb0 * vjb0 + vjb1 * vjb1);
+    double pe_before = (-G * mi * mj) / sqrt(d2 + soft);
+    double overlap = ((double)min_dist - dist) * pos_correct;
+    double nx = dvx / dist, ny = dvy / dist;
+    double ci = (mj / M) * overlap, cj = (mi / M) * overlap;
+    I.pos.x -= ci * nx; I.pos.y -= ci * ny;
+    J.pos.x += cj * nx; J.pos.y += cj * ny;
+    double fx = J.pos.x - I.pos.x, fy = J.pos.y - I.pos.y;
+    double fd2 = fx * fx + fy * fy;
+    double pe_after = (-G * mi * mj) / sqrt(fd2 + soft);
+    double pe_change = pe_after - pe_before;
+    double vrx = vjb0 - vib0, vry = vjb1 - vib1;
+    double vrn = vrx * nx + vry * ny;
+    if (vrn < 0) {
+        double imp = (-(1 + restitution) * mi * mj * vrn) / M;
+        double ii = imp / mi, ij = imp / mj;
+        I.vel.x -= ii * nx; I.vel.y -= ii * ny;
+        J.vel.x += ij * nx; J.vel.y += ij * ny;
+    }
+    double ke_after = 0.5 * mi * (I.vel.x * I.vel.x + I.vel.y * I.vel.y) +
+                      0.5 * mj * (J.vel.x * J.vel.x + J.vel.y * J.vel.y);
+    double ke_lost = ke_before - ke_after;
+    double heat = ke_lost - pe_change;
+    if (heat > 0) {
+        I.temp += (heat * 0.5) / mi;
+        J.temp += (heat * 0.5) / mj;
+    }
+    vals[0] = pe_change; vals[1] = ke_lost; vals[2] = heat;
+    return true;
+}
+
+// One round of executing the hypothesised contacts in dependency order: contact
+// h runs once the previous contact of each of its two slots ran in an EARLIER
+// round (done[] holds the round number, 0 = not yet).
+struct ContactSimulate {
+    int64_t n;
+    const uint32_t* hsi;
+    const uint32_t* hsj;
+    const int32_t* prev;
+    uint32_t* done;
+    uint32_t round;
+    BodyState* out;           // [2h + side]
+    double* vals;             // [3h]
+    uint32_t* executed;
+    // initial state
+    const uint32_t* cperm;
+    const vec2* cpos;
+    const int32_t* crad;
+    const vec2* vel;
+    const double* temp;
+    const double* mass;
+    double G, soft, restitution, pos_correct;
+    PSIM_HD BodyState fetch(uint32_t slot, int32_t pr) const
+    {
+        if (pr < 0) {
+            BodyState s;
+            uint32_t p = cperm[slot];
+            s.pos = cpos[slot];
+            s.vel = vel[p];
+            s.temp = temp[p];
+            return s;
+        }
+        int side = (hsi[pr] == slot) ? 0 : 1;
+        return out[2 * (uint32_t)pr + side];
+    }
+    PSIM_HD void operator()(int64_t h) const
+    {
+        if (done[h]) return;
+        int32_t pi = prev[2 * h], pj = prev[2 * h + 1];
+        if (pi >= 0) { uint32_t d = done[pi]; if (d == 0 || d == round) return; }
+        if (pj >= 0) { uint32_t d = done[pj]; if (d == 0 || d == round) return; }
+        uint32_t si = hsi[h], sj = hsj[h];
+        BodyState I = fetch(si, pi), J = fetch(sj, pj);
+        double v[3];
+        resolve_pair(I, J, mass[cperm[si]], mass[cperm[sj]], crad[si], crad[sj], G, soft, restitution,
+                     pos_correct, v);
+        out[2 * h] = I;
+        out[2 * h + 1] = J;
+        vals[3 * h] = v[0]; vals[3 * h + 1] = v[1]; vals[3 * h + 2] = v[2];
+        done[h] = round;
+        atomic_inc_u32(executed, 1);
+    }
+};
+
+// position of a slot as seen by the candidate pair with ordering key t: the
+// output of its last hypothesised contact ordered before t, else the initial one
+PSIM_HD PSIM_FORCEINLINE vec2 versioned_pos(uint32_t slot, uint64_t t, const int32_t* cseg, const uint64_t* adj,
+                                            int64_t n_adj, const uint64_t* hkeys, const uint32_t* hsi,
+                                            const BodyState* out, const vec2* cpos)
+{
+    int32_t e0 = cseg[slot];
+    int64_t last = -1;
+    if (e0 >= 0) {
+        for (int64_t e = e0; e < n_adj && (uint32_t)(adj[e] >> 32) == slot; ++e) {
+            uint32_t h = (uint32_t)adj[e];
+            if (hkeys[h] < t) last = h; else break;
+        }
+    }
+    if (last < 0) return cpos[slot];
+    int side = (hsi[last] == slot) ? 0 : 1;
+    return out[2 * last + side].pos;
+}
+
+// Re-test, against the versioned positions, every candidate pair that involves
+// a slot touched by a hypothesised contact.  Runs over adjacency entries; only
+// the first entry of a slot's segment works.  A pair of two touched slots is
+// emitted once, by the slot whose particle index is lower.
+struct ContactRetest {
+    int64_t n_adj;
+    GridView g;
+    const uint64_t* adj;
+    const int32_t* cseg;
+    const uint64_t* hkeys;
+    const uint32_t* hsi;
+    const BodyState* out;
+    const vec2* cpos;
+    const int32_t* crad;
+    uint64_t* out_keys;
+    uint32_t* counter;
+    uint32_t cap;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t x = (uint32_t)(adj[e] >> 32);
+        if (cseg[x] != (int32_t)e) return;
+        uint32_t px = g.cperm[x];
+        int32_t rx = crad[x];
+        const ContactRetest* self = this;
+        for_each_neighbour_slot(g, x, [=](uint32_t y) {
+            uint32_t py = self->g.cperm[y];
+            if (self->cseg[y] >= 0 && py < px) return;       // y's own pass emits it
+            uint64_t t = pair_key(self->g, x, y);
+            vec2 X = versioned_pos(x, t, self->cseg, self->adj, self->n_adj, self->hkeys, self->hsi,
+                                   self->out, self->cpos);
+            vec2 Y = versioned_pos(y, t, self->cseg, self->adj, self->n_adj, self->hkeys, self->hsi,
+                                   self->out, self->cpos);
+            bool hit = (px < py) ? in_contact(X, Y, rx, self->crad[y]) : in_contact(Y, X, self->crad[y], rx);
+            if (hit) {
+                uint32_t at = atomic_inc_u32(self->counter, 1);
+                if (at < self->cap) self->out_keys[at] = t;
+            }
+        });
+    }
+};
+
+// contacts of the initial-state sweep whose two slots are untouched by the
+// current hypothesis keep their initial status: carry them over
+struct ContactCarryClean {
+    int64_t n;
+    GridView g;
+    const uint64_t* h0keys;
+    const int32_t* cseg;
+    uint64_t* out_keys;
+    uint32_t* counter;
+    uint32_t cap;
+    PSIM_HD void operator()(int64_t h) const
+    {
+        uint32_t si, sj;
+        decode_pair_key(g, h0keys[h], &si, &sj);
+        if (cseg[si] < 0 && cseg[sj] < 0) {
+            uint32_t at = atomic_inc_u32(counter, 1);
+            if (at < cap) out_keys[at] = h0keys[h];
+        }
+    }
+};
+
+struct CompareKeys {
+    int64_t n;
+    const uint64_t* a;
+    const uint64_t* b;
+    uint32_t* mismatch;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        if (a[i] != b[i]) atomic_inc_u32(mismatch, 1);
+    }
+};
+
+struct ResetSeg {
+    int64_t n;
+    const uint64_t* adj;
+    int32_t* cseg;
+    PSIM_HD void operator()(int64_t e) const { cseg[(uint32_t)(adj[e] >> 32)] = -1; }
+};
+
+// converged: write each touched slot's final state back (index space + slot copy)
+struct ContactFinalize {
+    int64_t n_adj;
+    const uint64_t* adj;
+    int32_t* cseg;
+    const uint32_t* hsi;
+    const BodyState* out;
+    const uint32_t* cperm;
+    vec2* cpos;
+    vec2* pos;
+    vec2* vel;
+    double* temp;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t x = (uint32_t)(adj[e] >> 32);
+        bool last = (e + 1 == n_adj) || ((uint32_t)(adj[e + 1] >> 32) != x);
+        if (!last) return;
+        uint32_t h = (uint32_t)adj[e];
+        int side = (hsi[h] == x) ? 0 : 1;
+        BodyState s = out[2 * h + side];
+        uint32_t p = cperm[x];
+        cseg[x] = -1;
+        cpos[x] = s.pos;
+        pos[p] = s.pos;
+        vel[p] = s.vel;
+        temp[p] = s.temp;
+    }
+};
+
+// contact log (particle indices, per-contact energies) + summands of the
+// sweep totals (particle_system.py:165-168: heat only when > 0)
+struct ContactLog {
+    int64_t n;
+    const uint32_t* hsi;
+    const uint32_t* hsj;
+    const uint32_t* cperm;
+    const double* vals;
+    int32_t* log_ij;          // may be null
+    double* log_vals;         // may be null
+    int64_t log_base, log_cap;
+    double* sum_pe;
+    double* sum_ke;
+    double* sum_heat;
+    PSIM_HD void operator()(int64_t h) const
+    {
+        double pe = vals[3 * h], ke = vals[3 * h + 1], heat = vals[3 * h + 2];
+        sum_pe[h] = pe;
+        sum_ke[h] = ke;
+        sum_heat[h] = heat > 0 ? heat : 0.0;
+        int64_t at = log_base + h;
+        if (log_ij && at < log_cap) {
+            log_ij[2 * at] = (int32_t)cperm[hsi[h]];
+            log_ij[2 * at + 1] = (int32_t)cperm[hsj[h]];
+            log_vals[3 * at] = pe; log_vals[3 * at + 1] = ke; log_vals[3 * at + 2] = heat;
+        }
+    }
+};
+
+// --------------------------------------------------------------- stage 7/8: conduction + cooling
+struct GatherThermal {
+    int64_t n;
+    const uint32_t* cperm;
+    const double* temp;
+    const double* mass;
+    double* ctemp;
+    double* cmass;
+    PSIM_HD void operator()(int64_t k) const
+    {
+        uint32_t p = cperm[k];
+        ctemp[k] = temp[p];
+        cmass[k] = mass[p];
+    }
+};
+
+// particle_system.py:271-336 as a per-particle gather (Jacobi: reads the
+// pre-sweep temperatures, so the per-pair updates commute):
+//   touching iff d2 < (ri+rj)^2 ; E = k*(T_p1 - T_p2) ; dT_p1 -= E/m_p1 ; dT_p2 += E/m_p2
+// then :498 T += dT and :555-557 T *= (1 - damping).
+struct Conduction {
+    int64_t n;
+    GridView g;
+    const vec2* cpos;
+    const int32_t* crad;
+    const double* ctemp;
+    const double* cmass;
+    double heat_coeff;
+    double cool_factor;       // 1 - damping
+    int32_t do_conduct, do_cool;
+    double* temp;             // index space, written
+    double* delta_out;        // optional debug, index space
+    PSIM_HD void operator()(int64_t kk) const
+    {
+        uint32_t k = (uint32_t)kk;
+        uint32_t p = g.cperm[k];
+        double T = ctemp[k];
+        double delta = 0.0;
+        if (do_conduct) {
+            vec2 P = cpos[k];
+            int32_t rp = crad[k];
+            double m = cmass[k];
+            const Conduction* self = this;
+            double* dptr = &delta;
+            for_each_neighbour_slot(g, k, [=](uint32_t y) {
+                vec2 Q = self->cpos[y];
+                double dx = Q.x - P.x, dy = Q.y - P.y;
+                double d2 = dx * dx + dy * dy;
+                int64_t cd = (int64_t)rp + (int64_t)self->crad[y];
+                if (d2 < (double)(cd * cd)) {
+                    double Tq = self->ctemp[y];
+                    if (p < self->g.cperm[y]) {
+                        double diff = T - Tq;
+                        if (diff != 0) *dptr -= (self->heat_coeff * diff) / m;
+                    } else {
+                        double diff = Tq - T;
+                        if (diff != 0) *dptr += (self->heat_coeff * diff) / m;
+                    }
+                }
+            });
+        }
+        double T1 = T + delta;
+        if (do_cool) T1 = T1 * cool_factor;
+        temp[p] = T1;
+        if (delta_out) delta_out[p] = delta;
+    }
+};
+
+struct Cooling {
+    int64_t n;
+    double* temp;
+    double cool_factor;
+    PSIM_HD void operator()(int64_t i) const { temp[i] = temp[i] * cool_factor; }
+};
+
+// --------------------------------------------------------------- stage 9/10: walls, explosion flags
+// particle_system.py:500-516: both masks from the pre-clamp position, low clamp
+// then high clamp, velocity negated once if either fired.  Fused with the
+// explosion test particle_system.py:658 (T >= COLOR_MAX_TEMP).
+struct WallsFlag {
+    int64_t n;
+    vec2* pos;
+    vec2* vel;
+    const int32_t* radii;
+    const double* temp;
+    double W, H, explode_temp;
+    int32_t do_walls, do_flag;
+    uint8_t* boom;
+    uint32_t* boom_count;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        if (do_walls) {
+            vec2 p = pos[i], v = vel[i];
+            double r = (double)radii[i];
+            bool lo = (p.x - r) < 0, hi = (p.x + r) > W;
+            if (lo) p.x = r;
+            if (hi) p.x = W - r;
+            if (lo || hi) v.x *= -1;
+            bool lo2 = (p.y - r) < 0, hi2 = (p.y + r) > H;
+            if (lo2) p.y = r;
+            if (hi2) p.y = H - r;
+            if (lo2 || hi2) v.y *= -1;
+            if (lo || hi || lo2 || hi2) { pos[i] = p; vel[i] = v; }
+        }
+        if (do_flag) {
+            uint8_t b = temp[i] >= explode_temp ? 1 : 0;
+            boom[i] = b;
+            if (b) atomic_inc_u32(boom_count, 1);
+        }
+    }
+};
+
+// --------------------------------------------------------------- explosions
+struct FlagToU32 {
+    int64_t n;
+    const uint8_t* flag;
+    uint32_t* out;
+    int32_t invert;
+    PSIM_HD void operator()(int64_t i) const { out[i] = invert ? (flag[i] ? 0u : 1u) : (flag[i] ? 1u : 0u); }
+};
+
+struct ExploderList {
+    int64_t n;
+    const uint8_t* boom;
+    const uint32_t* rank;     // exclusive scan of boom
+    uint32_t* list;
+    PSIM_HD void operator()(int64_t i) const { if (boom[i]) list[rank[i]] = (uint32_t)i; }
+};
+
+// particle_system.py:667-702 for one exploding particle: neighbours from the
+// start-of-step grid (3x3 cells around int(x / cell_size), unclipped), minus
+// itself and other exploders; weights 1/d2 (d2 == 0 -> 1e-6).  Emits one
+// (neighbour << 32 | exploder rank) entry per affected neighbour.
+struct ExplosionGather {
+    int64_t n_ex;
+    const uint32_t* list;
+    GridView g;
+    double cell_size;
+    const vec2* pos;
+    const double* mass;
+    const double* temp;
+    const uint8_t* boom;
+    double efficiency;
+    double* ex_energy;
+    double* ex_total_w;
+    uint32_t* ex_count;
+    uint64_t* entries;
+    uint32_t* entry_counter;
+    uint32_t cap;
+    PSIM_HD void operator()(int64_t r) const
+    {
+        uint32_t p = list[r];
+        vec2 P = pos[p];
+        double energy = (mass[p] * temp[p]) * efficiency;
+        int64_t cx = (int64_t)(P.x / cell_size), cy = (int64_t)(P.y / cell_size);
+        double total = 0.0;
+        uint32_t cnt = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                int64_t x = cx + dx, y = cy + dy;
+                if (x < 0 || x >= g.gw || y < 0 || y >= g.gh) continue;
+                int64_t c = y * g.gw + x;
+                for (int32_t k = g.offsets[c]; k < g.offsets[c + 1]; ++k) {
+                    uint32_t q = g.cperm[k];
+                    if (q == p || boom[q]) continue;
+                    vec2 Q = pos[q];
+                    double ddx = Q.x - P.x, ddy = Q.y - P.y;
+                    double d2 = ddx * ddx + ddy * ddy;
+                    if (d2 == 0) d2 = 1e-6;
+                    total += 1.0 / d2;
+                    ++cnt;
+                    uint32_t at = atomic_inc_u32(entry_counter, 1);
+                    if (at < cap) entries[at] = ((uint64_t)q << 32) | (uint64_t)r;
+                }
+            }
+        ex_energy[r] = energy;
+        ex_total_w[r] = total;
+        ex_count[r] = cnt;
+    }
+};
+
+// particle_system.py:702-712: each affected neighbour receives its impulses in
+// ascending order of the exploding particle's index (entries are sorted).
+struct ExplosionApply {
+    int64_t n_entries;
+    const uint64_t* entries;
+    const uint32_t* list;
+    const vec2* pos;
+    const double* mass;
+    const double* ex_energy;
+    const double* ex_total_w;
+    vec2* vel;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t q = (uint32_t)(entries[e] >> 32);
+        if (e > 0 && (uint32_t)(entries[e - 1] >> 32) == q) return;
+        vec2 Q = pos[q], v = vel[q];
+        double mq = mass[q];
+        for (int64_t k = e; k < n_entries && (uint32_t)(entries[k] >> 32) == q; ++k) {
+            uint32_t r = (uint32_t)entries[k];
+            vec2 P = pos[list[r]];
+            double dx = Q.x - P.x, dy = Q.y - P.y;
+            double d2 = dx * dx + dy * dy;
+            if (d2 == 0) d2 = 1e-6;
+            double w = 1.0 / d2;
+            double share = ex_energy[r] * (w / ex_total_w[r]);
+            double dv = sqrt(2 * share / mq);
+            double dist = sqrt(d2);
+            v.x += (dx / dist) * dv;
+            v.y += (dy / dist) * dv;
+        }
+        vel[q] = v;
+    }
+};
+
+// particle_system.py:715-722: boolean-mask compaction, order preserved
+struct CompactState {
+    int64_t n;
+    const uint8_t* boom;
+    const uint32_t* new_index;   // exclusive scan of survivors
+    const vec2 *pos, *vel, *acc;
+    const double *mass, *inv_mass, *temp;
+    const int32_t* radii;
+    vec2 *pos_o, *vel_o, *acc_o;
+    double *mass_o, *inv_mass_o, *temp_o;
+    int32_t* radii_o;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        if (boom[i]) return;
+        uint32_t o = new_index[i];
+        pos_o[o] = pos[i]; vel_o[o] = vel[i]; acc_o[o] = acc[i];
+        mass_o[o] = mass[i]; inv_mass_o[o] = inv_mass[i]; temp_o[o] = temp[i];
+        radii_o[o] = radii[i];
+    }
+};
+
+// --------------------------------------------------------------- diagnostics
+// particle_system.py:765-783 summands + momentum
+struct EnergyTerms {
+    int64_t n;
+    const vec2* vel;
+    const double* mass;
+    const double* temp;
+    double* ke;
+    double* te;
+    double* px;
+    double* py;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        vec2 v = vel[i];
+        double m = mass[i];
+        ke[i] = 0.5 * m * (v.x * v.x + v.y * v.y);
+        te[i] = m * temp[i];
+        px[i] = m * v.x;
+        py[i] = m * v.y;
+    }
+};
+
+struct FillI32 {
+    int64_t n;
+    int32_t* p;
+    int32_t v;
+    PSIM_HD void operator()(int64_t i) const { p[i] = v; }
+};
+
+// upload helper: int64 radii of the reference (particle_system.py:376) -> int32
+struct ConvertRadii {
+    int64_t n;
+    const int64_t* in;
+    int32_t* out;
+    PSIM_HD void operator()(int64_t i) const { out[i] = (int32_t)in[i]; }
+};
+struct WidenRadii {
+    int64_t n;
+    const int32_t* in;
+    int64_t* out;
+    PSIM_HD void operator()(int64_t i) const { out[i] = (int64_t)in[i]; }
+};
+struct InverseMass {
+    int64_t n;
+    const double* mass;
+    double* inv;
+    PSIM_HD void operator()(int64_t i) const { inv[i] = 1.0 / mass[i]; }   // particle_system.py:374
+};
+
+}  // namespace psim

@@ -1,0 +1,618 @@
+// Host orchestration of one physics step on one device: owns the device
+// arrays and sequences the kernels in the reference's stage order
+// (particle_system.py:518-563).  Included by psim_capi.cpp after a back end.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "psim_kernels.h"
+
+namespace psim {
+
+struct Config {
+    double bounds_w, bounds_h;
+    double gravity_constant, softening, theta;
+    double heat_coeff, restitution, pos_correct, explosion_eff, damping, explode_temp;
+    int32_t cell_size, grid_w, grid_h, solver_iterations;
+    int32_t stage_mask;
+    int32_t walk_mode;      // 0: wave-cooperative walk, 1: one lane per particle
+    int32_t debug;          // keep per-step debug arrays (contact log, delta temps)
+    int32_t reserved;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { be::dev_free(p); }
+    // contents are NOT preserved on growth
+    void ensure(size_t n)
+    {
+        if (n > cap) {
+            be::dev_free(p);
+            p = nullptr;
+            size_t want = n + n / 8 + 64;
+            p = (T*)be::dev_alloc(want * sizeof(T));
+            cap = want;
+        }
+    }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
+};
+
+struct ExplosionEvent {
+    int32_t particle;       // index before compaction
+    int32_t neighbours;
+    double energy;
+};
+
+static inline int ceil_log2_u64(uint64_t v)
+{
+    int b = 0;
+    while (b < 63 && (1ull << b) < v) ++b;
+    return b;
+}
+
+class Sim {
+public:
+    Config cfg;
+    be::Stream st;
+    int64_t n = 0;
+    bool tree_valid = false;
+    int64_t tree_n = 0;            // particle count the tree / grid were built for
+    uint32_t n_internal = 0;
+    int sorted_key = 0, sorted_ckey = 0;
+
+    // state (index space; reference layout particle_system.py:370-376, radii narrowed)
+    DevBuf<vec2> pos, vel, acc, acc2;
+    DevBuf<double> mass, inv_mass, temp;
+    DevBuf<int32_t> radii;
+    // compaction targets
+    DevBuf<vec2> pos_b, vel_b, acc_b;
+    DevBuf<double> mass_b, inv_mass_b, temp_b;
+    DevBuf<int32_t> radii_b;
+
+    // Morton / tree
+    DevBuf<uint64_t> key[2];
+    DevBuf<uint32_t> perm[2];
+    DevBuf<vec2> spos;
+    DevBuf<double> smass;
+    DevBuf<int8_t> L;
+    DevBuf<uint32_t> owned, base;
+    DevBuf<NodeRec> rec;
+    DevBuf<uint32_t> node_first, node_last, node_depth[2], node_id[2];
+    DevBuf<double> pe_node;
+    DevBuf<int32_t> depth_off;
+    DevBuf<double> w2tab;
+    int32_t depth_off_host[40];
+
+    // grid
+    DevBuf<uint32_t> ckey[2], cperm[2];
+    DevBuf<int32_t> offsets;
+    DevBuf<vec2> cpos;
+    DevBuf<int32_t> crad;
+    DevBuf<double> ctemp, cmass;
+    DevBuf<int32_t> cseg;
+    bool cseg_ready = false;
+
+    // collisions
+    size_t ccap = 0;
+    DevBuf<uint64_t> h0[2], hc[2], hn[2], adj[2];
+    DevBuf<uint32_t> hsi, hsj, done;
+    DevBuf<int32_t> prevl;
+    DevBuf<BodyState> outst;
+    DevBuf<double> cvals, sum_pe, sum_ke, sum_heat;
+    DevBuf<int32_t> log_ij;
+    DevBuf<double> log_vals, delta_dbg;
+    int64_t log_n = 0;
+
+    // explosions
+    DevBuf<uint8_t> boom;
+    DevBuf<uint32_t> tmp32, tmp32b, ex_list, ex_count;
+    DevBuf<double> ex_energy, ex_total;
+    DevBuf<uint64_t> ex_entries[2];
+    size_t ecap = 0;
+    std::vector<ExplosionEvent> events;
+    std::vector<int32_t> last_exploded;
+
+    // scratch
+    DevBuf<uint32_t> sort_tmp, scan_tmp, counters;   // counters: 16 words
+    DevBuf<double> red_tmp, red_out, terms[4];
+
+    // per-step outputs
+    double coll_totals[3] = {0, 0, 0};
+    int64_t n_candidates = 0, n_contacts = 0, n_exploded = 0;
+    int64_t walk_visits = 0, walk_interactions = 0;
+    int64_t solver_rounds = 0, solver_fixpoint_iters = 0;
+    bool count_walk = false;
+    be::StageTimer timer;
+
+    ~Sim() { timer.destroy(); }
+
+    explicit Sim(const Config& c) : cfg(c), st(0)
+    {
+        counters.ensure(16);
+        red_tmp.ensure(be::kReduceBlocks);
+        red_out.ensure(8);
+        depth_off.ensure(40);
+        w2tab.ensure(kKeyLevels);
+        set_config(c);
+    }
+
+    void set_config(const Config& c)
+    {
+        if (c.grid_w <= 0 || c.grid_h <= 0 || c.cell_size <= 0) throw std::invalid_argument("psim: bad grid geometry");
+        if ((uint64_t)c.grid_w * (uint64_t)c.grid_h > kMaxCells) throw std::invalid_argument("psim: too many grid cells");
+        if (!(c.bounds_w > 0) || !(c.bounds_h > 0)) throw std::invalid_argument("psim: bounds must be positive");
+        bool geometry_changed = (c.grid_w != cfg.grid_w || c.grid_h != cfg.grid_h || c.cell_size != cfg.cell_size);
+        cfg = c;
+        if (geometry_changed) tree_n = 0;
+        double w2[kKeyLevels];
+        double w = c.bounds_w;
+        for (int d = 0; d < kKeyLevels; ++d) { w2[d] = w * w; w = w / 2; }   // quadtree.py:25,132 width halves per level
+        be::copy_h2d(st, w2tab.p, w2, sizeof(w2));
+        be::sync(st);
+    }
+
+    // -------------------------------------------------------------- state I/O
+    void upload(int64_t count, const double* h_pos, const double* h_vel, const double* h_acc, const double* h_mass,
+                const double* h_temp, const int64_t* h_radii)
+    {
+        if (count < 0 || count > 0x7fff0000LL) throw std::invalid_argument("psim: particle count out of range");
+        n = count;
+        size_t c = (size_t)count;
+        pos.ensure(c); vel.ensure(c); acc.ensure(c); acc2.ensure(c);
+        mass.ensure(c); inv_mass.ensure(c); temp.ensure(c); radii.ensure(c);
+        be::copy_h2d(st, pos.p, h_pos, c * 16);
+        if (h_vel) be::copy_h2d(st, vel.p, h_vel, c * 16); else be::dev_memset(st, vel.p, 0, c * 16);
+        if (h_acc) be::copy_h2d(st, acc.p, h_acc, c * 16); else be::dev_memset(st, acc.p, 0, c * 16);
+        be::copy_h2d(st, mass.p, h_mass, c * 8);
+        be::copy_h2d(st, temp.p, h_temp, c * 8);
+        DevBuf<int64_t> stage;
+        stage.ensure(c);
+        be::copy_h2d(st, stage.p, h_radii, c * 8);
+        be::launch(st, count, ConvertRadii{count, stage.p, radii.p});
+        be::launch(st, count, InverseMass{count, mass.p, inv_mass.p});
+        be::sync(st);
+        tree_valid = false;
+        tree_n = 0;
+        cseg_ready = false;
+    }
+
+    void download(double* h_pos, double* h_vel, double* h_acc, double* h_mass, double* h_inv_mass, double* h_temp,
+                  int64_t* h_radii)
+    {
+        size_t c = (size_t)n;
+        if (h_pos) be::copy_d2h(st, h_pos, pos.p, c * 16);
+        if (h_vel) be::copy_d2h(st, h_vel, vel.p, c * 16);
+        if (h_acc) be::copy_d2h(st, h_acc, acc.p, c * 16);
+        if (h_mass) be::copy_d2h(st, h_mass, mass.p, c * 8);
+        if (h_inv_mass) be::copy_d2h(st, h_inv_mass, inv_mass.p, c * 8);
+        if (h_temp) be::copy_d2h(st, h_temp, temp.p, c * 8);
+        if (h_radii) {
+            DevBuf<int64_t> stage;
+            stage.ensure(c);
+            be::launch(st, n, WidenRadii{n, radii.p, stage.p});
+            be::copy_d2h(st, h_radii, stage.p, c * 8);
+            be::sync(st);
+        }
+        be::sync(st);
+    }
+
+    uint32_t read_u32(const uint32_t* d)
+    {
+        uint32_t v = 0;
+        be::copy_d2h(st, &v, d, 4);
+        be::sync(st);
+        return v;
+    }
+
+    GridView grid_view() const
+    {
+        GridView g;
+        g.cperm = cperm[sorted_ckey].p;
+        g.ckey = ckey[sorted_ckey].p;
+        g.offsets = offsets.p;
+        g.gw = cfg.grid_w;
+        g.gh = cfg.grid_h;
+        return g;
+    }
+
+    // -------------------------------------------------------------- stages
+    void keys_and_drift(bool drift)
+    {
+        size_t c = (size_t)n;
+        key[0].ensure(c); key[1].ensure(c); perm[0].ensure(c); perm[1].ensure(c);
+        ckey[0].ensure(c); ckey[1].ensure(c); cperm[0].ensure(c); cperm[1].ensure(c);
+        DriftKeys k;
+        k.n = n; k.pos = pos.p; k.vel = vel.p; k.acc = acc.p;
+        k.key = key[0].p; k.perm = perm[0].p; k.ckey = ckey[0].p; k.cperm = cperm[0].p;
+        k.W = cfg.bounds_w; k.H = cfg.bounds_h; k.cell_size = (double)cfg.cell_size;
+        k.gw = cfg.grid_w; k.gh = cfg.grid_h; k.do_drift = drift ? 1 : 0;
+        be::launch(st, n, k);
+    }
+
+    // particle_system.py:732-763
+    void build_grid()
+    {
+        size_t c = (size_t)n;
+        uint64_t cells = (uint64_t)cfg.grid_w * (uint64_t)cfg.grid_h;
+        sort_tmp.ensure(be::sort_temp_words(c));
+        uint32_t* k[2] = {ckey[0].p, ckey[1].p};
+        uint32_t* v[2] = {cperm[0].p, cperm[1].p};
+        int bits = ceil_log2_u64(cells);
+        if (bits < 1) bits = 1;
+        sorted_ckey = be::radix_sort_pairs<uint32_t>(st, k, v, (uint64_t)n, 0, bits, sort_tmp.p);
+        offsets.ensure(cells + 1);
+        be::launch(st, n + 1, SegmentOffsets{n, ckey[sorted_ckey].p, offsets.p, (uint32_t)cells});
+        cpos.ensure(c); crad.ensure(c);
+        be::launch(st, n, GatherCell{n, cperm[sorted_ckey].p, pos.p, radii.p, cpos.p, crad.p});
+        tree_n = n;
+    }
+
+    // quadtree.py:177-196 (build) as sort + links + emit + bottom-up COM
+    void build_tree()
+    {
+        size_t c = (size_t)n;
+        tree_valid = false;
+        n_internal = 0;
+        if (n == 0) { tree_valid = true; return; }
+        sort_tmp.ensure(be::sort_temp_words(c));
+        uint64_t* k[2] = {key[0].p, key[1].p};
+        uint32_t* v[2] = {perm[0].p, perm[1].p};
+        sorted_key = be::radix_sort_pairs<uint64_t>(st, k, v, (uint64_t)n, 0, 64, sort_tmp.p);
+        const uint64_t* skey = key[sorted_key].p;
+        const uint32_t* sperm = perm[sorted_key].p;
+        spos.ensure(c); smass.ensure(c); L.ensure(c); owned.ensure(c); base.ensure(c);
+        be::launch(st, n, GatherTree{n, sperm, pos.p, mass.p, spos.p, smass.p});
+        be::launch(st, n, TreeLinks{n, skey, L.p, owned.p});
+        scan_tmp.ensure(be::scan_temp_words(c));
+        be::exclusive_scan_u32(st, owned.p, base.p, (uint64_t)n, scan_tmp.p, counters.p);
+        uint32_t m = read_u32(counters.p);
+        // the reference's pool holds 4N+1 nodes = at most N subdivided cells (quadtree.py:165)
+        if ((uint64_t)m > (uint64_t)n) throw std::runtime_error("psim: quadtree node pool overflow (near-coincident particles)");
+        n_internal = m;
+        size_t mm = m ? m : 1;
+        rec.ensure(c + mm);
+        node_first.ensure(mm); node_last.ensure(mm); node_depth[0].ensure(mm); node_depth[1].ensure(mm);
+        node_id[0].ensure(mm); node_id[1].ensure(mm); pe_node.ensure(mm);
+        TreeEmit e;
+        e.n = n; e.key = skey; e.L = L.p; e.owned = owned.p; e.base = base.p; e.spos = spos.p; e.smass = smass.p;
+        e.total_elems = (uint32_t)(n + m); e.rec = rec.p; e.node_first = node_first.p; e.node_last = node_last.p;
+        e.node_depth = node_depth[0].p; e.node_id = node_id[0].p;
+        be::launch(st, n, e);
+        if (m > 0) {
+            sort_tmp.ensure(be::sort_temp_words(mm));
+            uint32_t* dk[2] = {node_depth[0].p, node_depth[1].p};
+            uint32_t* dv[2] = {node_id[0].p, node_id[1].p};
+            int sd = be::radix_sort_pairs<uint32_t>(st, dk, dv, (uint64_t)m, 0, 8, sort_tmp.p);
+            be::launch(st, (int64_t)m + 1, SegmentOffsets{(int64_t)m, node_depth[sd].p, depth_off.p, (uint32_t)(kKeyLevels + 1)});
+            be::copy_d2h(st, depth_off_host, depth_off.p, sizeof(int32_t) * (kKeyLevels + 2));
+            be::sync(st);
+            for (int d = kMaxInternalDepth; d >= 0; --d) {
+                int64_t cnt = depth_off_host[d + 1] - depth_off_host[d];
+                if (cnt <= 0) continue;
+                TreeCom t;
+                t.count = cnt; t.ids = node_id[sd].p + depth_off_host[d]; t.depth = d; t.n = n; t.key = skey;
+                t.L = L.p; t.base = base.p; t.spos = spos.p; t.smass = smass.p; t.node_first = node_first.p;
+                t.node_last = node_last.p; t.rec = rec.p; t.pe_node = pe_node.p;
+                t.g_const = cfg.gravity_constant; t.softening = cfg.softening;
+                be::launch(st, cnt, t);
+            }
+        }
+        tree_valid = true;
+    }
+
+    void gravity(vec2* out);   // defined after the back end's walk kernel (psim_capi.cpp)
+
+    // particle_system.py:439-474
+    void ensure_contact_capacity(size_t want)
+    {
+        if (want <= ccap) return;
+        size_t c = want + want / 4 + 1024;
+        for (int i = 0; i < 2; ++i) { h0[i].ensure(c); hc[i].ensure(c); hn[i].ensure(c); adj[i].ensure(2 * c); }
+        hsi.ensure(c); hsj.ensure(c); done.ensure(c); prevl.ensure(2 * c); outst.ensure(2 * c); cvals.ensure(3 * c);
+        sum_pe.ensure(c); sum_ke.ensure(c); sum_heat.ensure(c);
+        sort_tmp.ensure(be::sort_temp_words(2 * c));
+        ccap = c;
+    }
+
+    void collisions()
+    {
+        coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0;
+        n_candidates = 0; n_contacts = 0; log_n = 0; solver_rounds = 0; solver_fixpoint_iters = 0;
+        if (n == 0) return;
+        if (!cseg_ready || cseg.cap < (size_t)n) {
+            cseg.ensure((size_t)n);
+            be::launch(st, (int64_t)cseg.cap, FillI32{(int64_t)cseg.cap, cseg.p, -1});
+            cseg_ready = true;
+        }
+        if (ccap == 0) ensure_contact_capacity((size_t)n / 16 + 1024);
+        for (int it = 0; it < cfg.solver_iterations; ++it) collision_sweep();
+    }
+
+    void collision_sweep()
+    {
+        GridView g = grid_view();
+        int key_bits = 40 + ceil_log2_u64((uint64_t)cfg.grid_w * cfg.grid_h);
+        if (key_bits > 64) key_bits = 64;
+        int adj_bits = 32 + ceil_log2_u64((uint64_t)n + 1);
+        // ---- sweep against the initial positions
+        uint32_t n0 = 0, cand = 0;
+        for (;;) {
+            be::dev_memset(st, counters.p, 0, 64);
+            ContactDetect d;
+            d.n = n; d.g = g; d.cpos = cpos.p; d.crad = crad.p; d.out_keys = h0[0].p; d.counter = counters.p;
+            d.cap = (uint32_t)ccap; d.cand_counter = cfg.debug ? counters.p + 1 : nullptr;
+            be::launch(st, n, d);
+            uint32_t two[2];
+            be::copy_d2h(st, two, counters.p, 8);
+            be::sync(st);
+            n0 = two[0]; cand = two[1];
+            if (n0 <= ccap) break;
+            ensure_contact_capacity(n0);
+        }
+        n_candidates += cand;
+        if (n0 == 0) return;
+        uint64_t* k0[2] = {h0[0].p, h0[1].p};
+        int s0 = be::radix_sort_pairs<uint64_t>(st, k0, nullptr, n0, 0, key_bits, sort_tmp.p);
+        const uint64_t* H0 = h0[s0].p;
+        be::copy_d2d(st, hc[0].p, H0, (size_t)n0 * 8);
+        uint64_t* H = hc[0].p;          // current hypothesis (sorted)
+        int hn_which = 0;
+        uint32_t nH = n0;
+        uint64_t* adjs = nullptr;
+        for (int iter = 0;; ++iter) {
+            ++solver_fixpoint_iters;
+            if (iter > 100000) throw std::runtime_error("psim: collision solver did not converge");
+            // ---- execute the hypothesis in order
+            be::launch(st, nH, ContactDecode{(int64_t)nH, g, H, hsi.p, hsj.p, adj[0].p, done.p});
+            uint64_t* ka[2] = {adj[0].p, adj[1].p};
+            int sa = be::radix_sort_pairs<uint64_t>(st, ka, nullptr, 2ull * nH, 0, adj_bits, sort_tmp.p);
+            adjs = adj[sa].p;
+            be::launch(st, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p});
+            uint32_t remaining = nH;
+            for (uint32_t round = 1; remaining > 0; ++round) {
+                be::dev_memset(st, counters.p, 0, 4);
+                ContactSimulate s;
+                s.n = nH; s.hsi = hsi.p; s.hsj = hsj.p; s.prev = prevl.p; s.done = done.p; s.round = round;
+                s.out = outst.p; s.vals = cvals.p; s.executed = counters.p; s.cperm = g.cperm; s.cpos = cpos.p;
+                s.crad = crad.p; s.vel = vel.p; s.temp = temp.p; s.mass = mass.p; s.G = cfg.gravity_constant;
+                s.soft = cfg.softening; s.restitution = cfg.restitution; s.pos_correct = cfg.pos_correct;
+                be::launch(st, nH, s);
+                uint32_t ex = read_u32(counters.p);
+                ++solver_rounds;
+                if (ex == 0 || ex > remaining) throw std::runtime_error("psim: internal: contact schedule stalled");
+                remaining -= ex;
+            }
+            // ---- re-test what the hypothesis could have changed
+            uint32_t nNew = 0;
+            for (;;) {
+                be::dev_memset(st, counters.p, 0, 4);
+                ContactRetest r;
+                r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outst.p;
+                r.cpos = cpos.p; r.crad = crad.p; r.out_keys = hn[0].p; r.counter = counters.p; r.cap = (uint32_t)ccap;
+                be::launch(st, 2ll * nH, r);
+                be::launch(st, n0, ContactCarryClean{(int64_t)n0, g, H0, cseg.p, hn[0].p, counters.p, (uint32_t)ccap});
+                nNew = read_u32(counters.p);
+                if (nNew <= ccap) break;
+                // growing reallocates every contact buffer: restart the whole sweep
+                be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+                ensure_contact_capacity(nNew);
+                collision_sweep();
+                return;
+            }
+            uint64_t* kn[2] = {hn[0].p, hn[1].p};
+            hn_which = be::radix_sort_pairs<uint64_t>(st, kn, nullptr, nNew, 0, key_bits, sort_tmp.p);
+            bool same = (nNew == nH);
+            if (same) {
+                be::dev_memset(st, counters.p, 0, 4);
+                be::launch(st, nH, CompareKeys{(int64_t)nH, H, hn[hn_which].p, counters.p});
+                same = read_u32(counters.p) == 0;
+            }
+            if (same) break;
+            be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+            be::copy_d2d(st, hc[0].p, hn[hn_which].p, (size_t)nNew * 8);
+            nH = nNew;
+            if (nH == 0) return;
+        }
+        // ---- converged: totals, log, write-back
+        size_t log_cap = 0;
+        if (cfg.debug) {
+            log_cap = (size_t)log_n + nH;
+            if (log_ij.cap < 2 * log_cap) {
+                DevBuf<int32_t> nij; DevBuf<double> nv;
+                nij.ensure(2 * log_cap); nv.ensure(3 * log_cap);
+                if (log_n) {
+                    be::copy_d2d(st, nij.p, log_ij.p, (size_t)log_n * 8);
+                    be::copy_d2d(st, nv.p, log_vals.p, (size_t)log_n * 24);
+                }
+                be::sync(st);
+                log_ij.swap(nij); log_vals.swap(nv);
+            }
+        }
+        ContactLog cl;
+        cl.n = nH; cl.hsi = hsi.p; cl.hsj = hsj.p; cl.cperm = g.cperm; cl.vals = cvals.p;
+        cl.log_ij = cfg.debug ? log_ij.p : nullptr; cl.log_vals = cfg.debug ? log_vals.p : nullptr;
+        cl.log_base = log_n; cl.log_cap = (int64_t)log_cap;
+        cl.sum_pe = sum_pe.p; cl.sum_ke = sum_ke.p; cl.sum_heat = sum_heat.p;
+        be::launch(st, nH, cl);
+        be::reduce_sum_f64(st, sum_pe.p, nH, red_tmp.p, red_out.p);
+        be::reduce_sum_f64(st, sum_ke.p, nH, red_tmp.p, red_out.p + 1);
+        be::reduce_sum_f64(st, sum_heat.p, nH, red_tmp.p, red_out.p + 2);
+        ContactFinalize f;
+        f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outst.p; f.cperm = g.cperm;
+        f.cpos = cpos.p; f.pos = pos.p; f.vel = vel.p; f.temp = temp.p;
+        be::launch(st, 2ll * nH, f);
+        be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+        double t[3];
+        be::copy_d2h(st, t, red_out.p, 24);
+        be::sync(st);
+        coll_totals[0] += t[0]; coll_totals[1] += t[1]; coll_totals[2] += t[2];
+        n_contacts += nH;
+        if (cfg.debug) log_n += nH;
+    }
+
+    // particle_system.py:476-498 + :555-557
+    void conduction_and_cooling()
+    {
+        bool cond = (cfg.stage_mask & kStageConduction) != 0;
+        bool cool = (cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0;
+        if (n == 0 || (!cond && !cool)) return;
+        double factor = 1.0 - cfg.damping;
+        if (!cond) {
+            be::launch(st, n, Cooling{n, temp.p, factor});
+            return;
+        }
+        size_t c = (size_t)n;
+        ctemp.ensure(c); cmass.ensure(c);
+        GridView g = grid_view();
+        be::launch(st, n, GatherThermal{n, g.cperm, temp.p, mass.p, ctemp.p, cmass.p});
+        if (cfg.debug) delta_dbg.ensure(c);
+        Conduction k;
+        k.n = n; k.g = g; k.cpos = cpos.p; k.crad = crad.p; k.ctemp = ctemp.p; k.cmass = cmass.p;
+        k.heat_coeff = cfg.heat_coeff; k.cool_factor = factor; k.do_conduct = 1; k.do_cool = cool ? 1 : 0;
+        k.temp = temp.p; k.delta_out = cfg.debug ? delta_dbg.p : nullptr;
+        be::launch(st, n, k);
+    }
+
+    // particle_system.py:500-516 and the explosion test of :658
+    uint32_t walls_and_flags()
+    {
+        bool w = (cfg.stage_mask & kStageWalls) != 0, f = (cfg.stage_mask & kStageExplosions) != 0;
+        if (n == 0 || (!w && !f)) return 0;
+        boom.ensure((size_t)n);
+        be::dev_memset(st, counters.p, 0, 4);
+        WallsFlag k;
+        k.n = n; k.pos = pos.p; k.vel = vel.p; k.radii = radii.p; k.temp = temp.p; k.W = cfg.bounds_w;
+        k.H = cfg.bounds_h; k.explode_temp = cfg.explode_temp; k.do_walls = w; k.do_flag = f; k.boom = boom.p;
+        k.boom_count = counters.p;
+        be::launch(st, n, k);
+        return f ? read_u32(counters.p) : 0;
+    }
+
+    // particle_system.py:651-730
+    void explosions(uint32_t count)
+    {
+        size_t c = (size_t)n;
+        GridView g = grid_view();
+        tmp32.ensure(c); tmp32b.ensure(c); scan_tmp.ensure(be::scan_temp_words(c));
+        ex_list.ensure(count); ex_count.ensure(count); ex_energy.ensure(count); ex_total.ensure(count);
+        be::launch(st, n, FlagToU32{n, boom.p, tmp32.p, 0});
+        be::exclusive_scan_u32(st, tmp32.p, tmp32b.p, (uint64_t)n, scan_tmp.p, nullptr);
+        be::launch(st, n, ExploderList{n, boom.p, tmp32b.p, ex_list.p});
+        if (ecap == 0) { ecap = (size_t)count * 64 + 1024; ex_entries[0].ensure(ecap); ex_entries[1].ensure(ecap); }
+        uint32_t ne = 0;
+        for (;;) {
+            be::dev_memset(st, counters.p, 0, 4);
+            ExplosionGather k;
+            k.n_ex = count; k.list = ex_list.p; k.g = g; k.cell_size = (double)cfg.cell_size; k.pos = pos.p;
+            k.mass = mass.p; k.temp = temp.p; k.boom = boom.p; k.efficiency = cfg.explosion_eff;
+            k.ex_energy = ex_energy.p; k.ex_total_w = ex_total.p; k.ex_count = ex_count.p;
+            k.entries = ex_entries[0].p; k.entry_counter = counters.p; k.cap = (uint32_t)ecap;
+            be::launch(st, count, k);
+            ne = read_u32(counters.p);
+            if (ne <= ecap) break;
+            ecap = (size_t)ne + ne / 4 + 1024;
+            ex_entries[0].ensure(ecap); ex_entries[1].ensure(ecap);
+        }
+        if (ne > 0) {
+            sort_tmp.ensure(be::sort_temp_words(ne));
+            uint64_t* ke[2] = {ex_entries[0].p, ex_entries[1].p};
+            int bits = 32 + ceil_log2_u64((uint64_t)n + 1);
+            int se = be::radix_sort_pairs<uint64_t>(st, ke, nullptr, ne, 0, bits, sort_tmp.p);
+            be::launch(st, ne, ExplosionApply{(int64_t)ne, ex_entries[se].p, ex_list.p, pos.p, mass.p, ex_energy.p,
+                                              ex_total.p, vel.p});
+        }
+        // events for the host-side log (particle_system.py:683-689)
+        std::vector<uint32_t> hl(count), hc2(count);
+        std::vector<double> he(count);
+        be::copy_d2h(st, hl.data(), ex_list.p, (size_t)count * 4);
+        be::copy_d2h(st, hc2.data(), ex_count.p, (size_t)count * 4);
+        be::copy_d2h(st, he.data(), ex_energy.p, (size_t)count * 8);
+        be::sync(st);
+        last_exploded.resize(count);
+        for (uint32_t i = 0; i < count; ++i) {
+            events.push_back(ExplosionEvent{(int32_t)hl[i], (int32_t)hc2[i], he[i]});
+            last_exploded[i] = (int32_t)hl[i];
+        }
+        // compaction
+        pos_b.ensure(c); vel_b.ensure(c); acc_b.ensure(c); mass_b.ensure(c); inv_mass_b.ensure(c); temp_b.ensure(c);
+        radii_b.ensure(c);
+        be::launch(st, n, FlagToU32{n, boom.p, tmp32.p, 1});
+        be::exclusive_scan_u32(st, tmp32.p, tmp32b.p, (uint64_t)n, scan_tmp.p, nullptr);
+        CompactState k;
+        k.n = n; k.boom = boom.p; k.new_index = tmp32b.p; k.pos = pos.p; k.vel = vel.p; k.acc = acc.p; k.mass = mass.p;
+        k.inv_mass = inv_mass.p; k.temp = temp.p; k.radii = radii.p; k.pos_o = pos_b.p; k.vel_o = vel_b.p;
+        k.acc_o = acc_b.p; k.mass_o = mass_b.p; k.inv_mass_o = inv_mass_b.p; k.temp_o = temp_b.p; k.radii_o = radii_b.p;
+        be::launch(st, n, k);
+        pos.swap(pos_b); vel.swap(vel_b); acc.swap(acc_b); mass.swap(mass_b); inv_mass.swap(inv_mass_b);
+        temp.swap(temp_b); radii.swap(radii_b);
+        acc2.ensure(c);
+        n -= count;
+        n_exploded = count;
+    }
+
+    // -------------------------------------------------------------- entry points
+    // particle_system.py:409-437 for a freshly built tree (as main.py:151 uses it)
+    void prime_gravity()
+    {
+        keys_and_drift(false);
+        build_tree();
+        gravity(acc.p);
+        be::sync(st);
+    }
+
+    // particle_system.py:518-563
+    void step()
+    {
+        n_exploded = 0;
+        last_exploded.clear();
+        timer.mark(st, 0);
+        keys_and_drift(true);
+        timer.mark(st, 1);
+        build_grid();
+        timer.mark(st, 2);
+        build_tree();
+        timer.mark(st, 3);
+        gravity(acc2.p);
+        timer.mark(st, 4);
+        be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
+        acc.swap(acc2);
+        timer.mark(st, 5);
+        if (cfg.stage_mask & kStageCollisions) collisions();
+        else { coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0; n_candidates = n_contacts = 0; log_n = 0; }
+        timer.mark(st, 6);
+        conduction_and_cooling();
+        timer.mark(st, 7);
+        uint32_t nb = walls_and_flags();
+        if (nb > 0) explosions(nb);
+        timer.mark(st, 8);
+    }
+
+    // particle_system.py:765-804 (+ total momentum)
+    void energies(double* out5)
+    {
+        out5[0] = out5[1] = out5[2] = out5[3] = out5[4] = 0.0;
+        if (n > 0) {
+            for (int i = 0; i < 4; ++i) terms[i].ensure((size_t)n);
+            be::launch(st, n, EnergyTerms{n, vel.p, mass.p, temp.p, terms[0].p, terms[1].p, terms[2].p, terms[3].p});
+            for (int i = 0; i < 4; ++i) be::reduce_sum_f64(st, terms[i].p, (uint64_t)n, red_tmp.p, red_out.p + i);
+        } else {
+            be::dev_memset(st, red_out.p, 0, 32);
+        }
+        if (tree_valid && n_internal > 0) be::reduce_sum_f64(st, pe_node.p, n_internal, red_tmp.p, red_out.p + 4);
+        else be::dev_memset(st, red_out.p + 4, 0, 8);
+        double t[5];
+        be::copy_d2h(st, t, red_out.p, 40);
+        be::sync(st);
+        out5[0] = t[0]; out5[1] = t[4]; out5[2] = t[1]; out5[3] = t[2]; out5[4] = t[3];
+    }
+};
+
+}  // namespace psim

@@ -1,0 +1,57 @@
+// Shared plain types of the psim HIP library.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(PSIM_HOSTLOOP)
+// Test-only build: kernel bodies run as host loops (tests/hostloop).  Never shipped.
+#define PSIM_HD
+#define PSIM_FORCEINLINE inline
+#else
+#include <hip/hip_runtime.h>
+#define PSIM_HD __host__ __device__
+#define PSIM_FORCEINLINE __forceinline__
+#endif
+
+namespace psim {
+
+struct alignas(16) vec2 {
+    double x, y;
+};
+
+// One element of the pre-order quadtree array: an internal node (depth 0..31)
+// or a particle leaf (depth == kLeaf).  skip = index of the first element after
+// this element's subtree.  32 bytes, so a wave-uniform fetch is one 32-B load.
+struct alignas(32) NodeRec {
+    double mass, x, y;
+    uint32_t skip;
+    uint32_t depth;
+};
+
+constexpr uint32_t kLeaf = 255;
+constexpr int kKeyLevels = 32;          // Morton key: 32 levels x 2 bits
+constexpr int kMaxInternalDepth = 31;   // children of depth-31 nodes are bucket leaves
+
+// ordering key of a candidate pair inside one collision sweep
+// (cell:24 | phase:4 | a:18 | b:18), see pair_key()
+constexpr int kSlotBits = 18;
+constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1;
+constexpr uint32_t kMaxCellOccupancy = kSlotMask;   // per-cell particle limit
+constexpr uint32_t kMaxCells = 1u << 24;
+
+enum StageBits : int32_t {
+    kStageCollisions = 1,
+    kStageConduction = 2,
+    kStageCooling = 4,
+    kStageWalls = 8,
+    kStageExplosions = 16,
+    kStageAll = 31,
+};
+
+// per-contact record produced by the collision solver
+struct BodyState {
+    vec2 pos, vel;
+    double temp;
+};
+
+}  // namespace psim

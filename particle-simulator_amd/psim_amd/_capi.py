@@ -1,0 +1,106 @@
+"""ctypes binding of the C ABI declared in include/psim.h.
+
+The product loads libpsim_hip.so from this directory and nothing else: if the
+HIP extension is missing or fails to load, importing the simulator raises.
+There is no CPU fallback.  (`load(path)` with an explicit path exists so the CPU
+test-suite can bind the test-only host-loop build of the same sources.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIBRARY = os.path.join(_HERE, "libpsim_hip.so")
+
+STAGE_COLLISIONS = 1
+STAGE_CONDUCTION = 2
+STAGE_COOLING = 4
+STAGE_WALLS = 8
+STAGE_EXPLOSIONS = 16
+STAGE_ALL = 31
+
+EXPORTS = [
+    "psim_create", "psim_destroy", "psim_set_config", "psim_upload", "psim_download",
+    "psim_num_particles", "psim_prime_gravity", "psim_step", "psim_energies",
+    "psim_collision_stats", "psim_counts", "psim_explosion_events", "psim_walk_counts",
+    "psim_debug_size", "psim_debug_fetch", "psim_selftest", "psim_stage_times",
+    "psim_last_error", "psim_version",
+]
+
+
+class PsimConfig(ctypes.Structure):
+    """struct psim_config (include/psim.h)."""
+    _fields_ = [
+        ("bounds_w", ctypes.c_double), ("bounds_h", ctypes.c_double),
+        ("gravity_constant", ctypes.c_double), ("softening", ctypes.c_double),
+        ("theta", ctypes.c_double), ("heat_coeff", ctypes.c_double),
+        ("restitution", ctypes.c_double), ("pos_correct", ctypes.c_double),
+        ("explosion_eff", ctypes.c_double), ("damping", ctypes.c_double),
+        ("explode_temp", ctypes.c_double),
+        ("cell_size", ctypes.c_int32), ("grid_w", ctypes.c_int32), ("grid_h", ctypes.c_int32),
+        ("solver_iterations", ctypes.c_int32), ("stage_mask", ctypes.c_int32),
+        ("walk_mode", ctypes.c_int32), ("debug", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+class ExplosionEvent(ctypes.Structure):
+    _fields_ = [("particle", ctypes.c_int32), ("neighbours", ctypes.c_int32),
+                ("energy", ctypes.c_double)]
+
+
+class PsimError(RuntimeError):
+    pass
+
+
+_libs = {}
+
+
+def load(path=None):
+    """Load and type the library.  Raises ImportError when it cannot be loaded."""
+    path = path or HIP_LIBRARY
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise ImportError(
+            "psim: HIP extension %s not found -- build it with "
+            "`make -C particle-simulator_amd/csrc` (there is no CPU fallback)" % path)
+    try:
+        L = ctypes.CDLL(path)
+    except OSError as e:
+        raise ImportError("psim: cannot load %s: %s" % (path, e))
+    c_dp = ctypes.POINTER(ctypes.c_double)
+    c_ip = ctypes.POINTER(ctypes.c_int64)
+    vp = ctypes.c_void_p
+    L.psim_create.argtypes = [ctypes.POINTER(PsimConfig), ctypes.c_int, ctypes.POINTER(vp)]
+    L.psim_destroy.argtypes = [vp]
+    L.psim_set_config.argtypes = [vp, ctypes.POINTER(PsimConfig)]
+    L.psim_upload.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp]
+    L.psim_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.psim_num_particles.argtypes = [vp]
+    L.psim_num_particles.restype = ctypes.c_int64
+    L.psim_prime_gravity.argtypes = [vp]
+    L.psim_step.argtypes = [vp, ctypes.c_int64]
+    L.psim_energies.argtypes = [vp, c_dp]
+    L.psim_collision_stats.argtypes = [vp, c_dp]
+    L.psim_counts.argtypes = [vp, c_ip]
+    L.psim_explosion_events.argtypes = [vp, ctypes.POINTER(ExplosionEvent), ctypes.c_int64]
+    L.psim_explosion_events.restype = ctypes.c_int64
+    L.psim_walk_counts.argtypes = [vp, c_ip]
+    L.psim_debug_size.argtypes = [vp, ctypes.c_char_p]
+    L.psim_debug_size.restype = ctypes.c_int64
+    L.psim_debug_fetch.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t]
+    L.psim_selftest.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_uint64]
+    L.psim_stage_times.argtypes = [vp, c_dp]
+    L.psim_last_error.restype = ctypes.c_char_p
+    L.psim_version.restype = ctypes.c_char_p
+    for name in EXPORTS:
+        getattr(L, name)     # AttributeError here = library does not export the declared ABI
+    _libs[path] = L
+    return L
+
+
+def check(L, rc):
+    if rc != 0:
+        msg = L.psim_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise PsimError(msg)

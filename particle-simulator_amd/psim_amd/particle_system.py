@@ -1,0 +1,335 @@
+"""`ParticleSystem` with the constructor, attributes and methods of the
+reference class (particle_system.py:339-804), driving the HIP library through
+the C ABI of include/psim.h.  main.py of the reference runs unchanged on it:
+
+    from psim_amd.particle_system import ParticleSystem
+
+State lives on the GPU.  The public arrays (`positions`, `velocities`,
+`accelerations`, `masses`, `inverse_masses`, `temperatures`, `radii`) are host
+NumPy arrays refreshed lazily: reading one after `update()` downloads the
+current state once.  Writes to them are pushed with `push_state()`.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from . import _capi
+from . import constants
+
+logger = logging.getLogger("particle_sim")
+
+
+def grid_geometry(config, bounds):
+    """Cell size and grid shape exactly as particle_system.py:381-390."""
+    max_radius = np.sqrt(config['max_mass']).astype(int)
+    base_cell_size = max_radius * 2
+    multiplier = config.get('grid_cell_size_multiplier', 1.0)
+    cell_size = int(base_cell_size * multiplier)
+    if cell_size == 0:
+        cell_size = 10
+    b = np.array(bounds)
+    return cell_size, int(np.ceil(b[0] / cell_size)), int(np.ceil(b[1] / cell_size))
+
+
+def make_config(config, bounds, stage_mask=_capi.STAGE_ALL, walk_mode=0, debug=False):
+    """dict from config.json's "simulation" section -> struct psim_config.
+    Required and optional keys and their defaults follow particle_system.py:359-361,
+    383, 397, 430-431, 462, 555, 673."""
+    cell_size, gw, gh = grid_geometry(config, bounds)
+    c = _capi.PsimConfig()
+    c.bounds_w, c.bounds_h = float(bounds[0]), float(bounds[1])
+    c.gravity_constant = float(config['gravity_constant'])
+    c.softening = float(config['softening_factor'])
+    c.theta = float(config['barnes_hut_theta'])
+    c.heat_coeff = float(config['heat_transfer_coefficient'])
+    c.restitution = float(config['coefficient_of_restitution'])
+    c.pos_correct = float(config.get('position_correction_factor', 1.0))
+    c.explosion_eff = float(config.get('explosion_efficiency', 0.1))
+    c.damping = float(config.get('thermal_damping_factor', 0.0))
+    c.explode_temp = float(constants.COLOR_MAX_TEMP)
+    c.cell_size, c.grid_w, c.grid_h = cell_size, gw, gh
+    c.solver_iterations = int(config.get('collision_solver_iterations', 1))
+    c.stage_mask = int(stage_mask)
+    c.walk_mode = int(walk_mode)
+    c.debug = 1 if debug else 0
+    return c
+
+
+_FIELDS = ("positions", "velocities", "accelerations", "masses", "inverse_masses",
+           "temperatures", "radii")
+
+
+class ParticleSystem:
+    def __init__(self, num_particles: int, config: dict, rng: np.random.Generator, bounds: tuple,
+                 *, device: int = 0, stage_mask: int = _capi.STAGE_ALL, walk_mode: int = 0,
+                 debug: bool = False, state: dict = None, library: str = None):
+        """Positional arguments as particle_system.py:355.  Keyword-only extras:
+        device ordinal, stage mask (benchmarks), tree-walk variant, debug arrays,
+        an explicit initial `state` dict (positions, masses, temperatures[,
+        velocities, accelerations]) instead of the RNG draws, and the library path
+        (CPU test-suite only)."""
+        self._lib = _capi.load(library)
+        self.num_particles = int(num_particles)
+        self.config = config
+        self.bounds = np.array(bounds)
+        self.restitution = config['coefficient_of_restitution']
+        self.position_correction_factor = config.get('position_correction_factor', 1.0)
+        self.collision_solver_iterations = config.get('collision_solver_iterations', 1)
+        self.barnes_hut_theta = config['barnes_hut_theta']
+        self.pe_gain_collisions = 0.0
+        self.ke_loss_collisions = 0.0
+        self.heat_generated_collisions = 0.0
+        self._stage_mask, self._walk_mode, self._debug = stage_mask, walk_mode, debug
+        self._device = device
+        n = self.num_particles
+
+        if state is None:
+            # the three draws, in the reference's order (particle_system.py:370,373,375)
+            positions = rng.random((n, 2)) * self.bounds
+            masses = rng.uniform(config['min_mass'], config['max_mass'], (n, 1))
+            temperatures = rng.uniform(config['min_temp'], config['max_temp'], (n, 1))
+            velocities = np.zeros((n, 2), dtype=float)
+            accelerations = np.zeros((n, 2), dtype=float)
+        else:
+            positions = np.ascontiguousarray(state['positions'], dtype=np.float64).reshape(n, 2)
+            masses = np.ascontiguousarray(state['masses'], dtype=np.float64).reshape(n, 1)
+            temperatures = np.ascontiguousarray(state['temperatures'], dtype=np.float64).reshape(n, 1)
+            velocities = np.ascontiguousarray(state.get('velocities', np.zeros((n, 2))), dtype=np.float64).reshape(n, 2)
+            accelerations = np.ascontiguousarray(state.get('accelerations', np.zeros((n, 2))), dtype=np.float64).reshape(n, 2)
+        radii = np.sqrt(masses).astype(int)                 # particle_system.py:376 (int64)
+
+        self.cell_size, self.grid_width, self.grid_height = grid_geometry(config, bounds)
+        self._cfg = make_config(config, bounds, stage_mask, walk_mode, debug)
+        self._cfg_key = self._config_key()
+        self._ctx = ctypes.c_void_p()
+        _capi.check(self._lib, self._lib.psim_create(ctypes.byref(self._cfg), device, ctypes.byref(self._ctx)))
+        self._host = dict(positions=positions, velocities=velocities, accelerations=accelerations,
+                          masses=masses, inverse_masses=1.0 / masses, temperatures=temperatures,
+                          radii=radii.astype(np.int64))
+        self._stale = False
+        self._upload()
+        logger.info(f"ParticleSystem created for {num_particles} particles.")
+        logger.info(f"Spatial grid initialized with cell size {self.cell_size} "
+                    f"({self.grid_width}x{self.grid_height} cells).")
+
+    # ------------------------------------------------------------------ plumbing
+    def _config_key(self):
+        c = self.config
+        return (c['gravity_constant'], c['softening_factor'], c['barnes_hut_theta'],
+                c['heat_transfer_coefficient'], c['coefficient_of_restitution'],
+                c.get('position_correction_factor', 1.0), c.get('explosion_efficiency', 0.1),
+                c.get('thermal_damping_factor', 0.0), c.get('collision_solver_iterations', 1))
+
+    def _sync_config(self):
+        """The reference holds the config dict by reference and re-reads it every
+        step (particle_system.py:430,462,555,673): push it when it changed."""
+        key = self._config_key()
+        if key != self._cfg_key:
+            self._cfg = make_config(self.config, self.bounds, self._stage_mask, self._walk_mode, self._debug)
+            _capi.check(self._lib, self._lib.psim_set_config(self._ctx, ctypes.byref(self._cfg)))
+            self._cfg_key = key
+
+    def _ptr(self, name):
+        return self._host[name].ctypes.data_as(ctypes.c_void_p)
+
+    def _upload(self):
+        h = self._host
+        for k in _FIELDS:
+            h[k] = np.ascontiguousarray(h[k])
+        _capi.check(self._lib, self._lib.psim_upload(
+            self._ctx, self.num_particles, self._ptr("positions"), self._ptr("velocities"),
+            self._ptr("accelerations"), self._ptr("masses"), self._ptr("temperatures"), self._ptr("radii")))
+        self._stale = False
+
+    def push_state(self):
+        """Upload the host arrays after the caller modified them in place."""
+        self._refresh()
+        self._upload()
+
+    def _refresh(self):
+        if not self._stale:
+            return
+        n = int(self._lib.psim_num_particles(self._ctx))
+        h = self._host
+        if n != h["positions"].shape[0]:
+            # the reference rebinds (does not resize) its arrays on explosion (:716-722)
+            h["positions"] = np.empty((n, 2)); h["velocities"] = np.empty((n, 2))
+            h["accelerations"] = np.empty((n, 2)); h["masses"] = np.empty((n, 1))
+            h["inverse_masses"] = np.empty((n, 1)); h["temperatures"] = np.empty((n, 1))
+            h["radii"] = np.empty((n, 1), dtype=np.int64)
+        _capi.check(self._lib, self._lib.psim_download(
+            self._ctx, self._ptr("positions"), self._ptr("velocities"), self._ptr("accelerations"),
+            self._ptr("masses"), self._ptr("inverse_masses"), self._ptr("temperatures"), self._ptr("radii")))
+        self._stale = False
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.psim_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference surface
+    def _calculate_gravity(self):
+        """particle_system.py:409-437 (main.py:151 primes a(0) with it)."""
+        self._sync_config()
+        _capi.check(self._lib, self._lib.psim_prime_gravity(self._ctx))
+        self._stale = True
+
+    def update(self, steps: int = 1):
+        """particle_system.py:518-563.  `steps` > 1 runs several updates in one call."""
+        self._sync_config()
+        _capi.check(self._lib, self._lib.psim_step(self._ctx, int(steps)))
+        self._stale = True
+        t = (ctypes.c_double * 3)()
+        _capi.check(self._lib, self._lib.psim_collision_stats(self._ctx, t))
+        self.pe_gain_collisions, self.ke_loss_collisions, self.heat_generated_collisions = t[0], t[1], t[2]
+        old = self.num_particles
+        self.num_particles = int(self._lib.psim_num_particles(self._ctx))
+        self._drain_explosion_log(old)
+
+    def _drain_explosion_log(self, old_count):
+        """Log lines of particle_system.py:683-689,727-730."""
+        buf = (_capi.ExplosionEvent * 256)()
+        total = 0
+        while True:
+            k = int(self._lib.psim_explosion_events(self._ctx, buf, 256))
+            if k <= 0:
+                break
+            total += k
+            for e in buf[:k]:
+                if e.neighbours == 0:
+                    logger.warning(f"Particle {e.particle} exploded with no valid neighbors. Energy was lost.")
+                else:
+                    logger.info(f"Particle {e.particle} exploded with {e.energy:.1f} thermal energy, "
+                                f"affecting {e.neighbours} neighbors.")
+        if total and self.num_particles != old_count:
+            logger.info(f"{old_count - self.num_particles} particle(s) removed by explosion. "
+                        f"New count: {self.num_particles}.")
+
+    def _energies(self):
+        out = (ctypes.c_double * 5)()
+        _capi.check(self._lib, self._lib.psim_energies(self._ctx, out))
+        return list(out)
+
+    def get_total_kinetic_energy(self):
+        return self._energies()[0]
+
+    def get_total_potential_energy(self):
+        return self._energies()[1]
+
+    def get_total_thermal_energy(self):
+        return self._energies()[2]
+
+    def get_energies(self):
+        """(KE, PE, TE) in one call."""
+        return tuple(self._energies()[:3])
+
+    def get_total_momentum(self):
+        e = self._energies()
+        return e[3], e[4]
+
+    # ------------------------------------------------------------------ diagnostics
+    def counts(self):
+        out = (ctypes.c_int64 * 8)()
+        _capi.check(self._lib, self._lib.psim_counts(self._ctx, out))
+        keys = ("particles", "tree_nodes", "candidates", "contacts", "exploded", "internal_nodes",
+                "solver_iterations", "solver_rounds")
+        return dict(zip(keys, out))
+
+    def walk_counts(self):
+        out = (ctypes.c_int64 * 2)()
+        _capi.check(self._lib, self._lib.psim_walk_counts(self._ctx, out))
+        return int(out[0]), int(out[1])
+
+    def stage_times_ms(self):
+        out = (ctypes.c_double * 8)()
+        _capi.check(self._lib, self._lib.psim_stage_times(self._ctx, out))
+        keys = ("drift_keys", "grid", "tree", "gravity", "kick", "collisions", "conduction", "walls_explosions")
+        return dict(zip(keys, out))
+
+    _DEBUG_DTYPES = {
+        "key": (np.uint64, ()), "perm": (np.uint32, ()), "L": (np.int8, ()), "owned": (np.uint32, ()),
+        "base": (np.uint32, ()), "rec": (np.dtype([("mass", "f8"), ("x", "f8"), ("y", "f8"),
+                                                   ("skip", "u4"), ("depth", "u4")]), ()),
+        "node_first": (np.uint32, ()), "node_last": (np.uint32, ()), "node_depth": (np.uint32, ()),
+        "depth_offsets": (np.int32, ()), "grid_offsets": (np.int32, ()), "grid_indices": (np.int32, ()),
+        "cell_key": (np.uint32, ()), "contact_ij": (np.int32, (2,)), "contact_vals": (np.float64, (3,)),
+        "delta_temps": (np.float64, ()), "exploded": (np.int32, ()),
+    }
+
+    def debug_array(self, name):
+        dtype, tail = self._DEBUG_DTYPES[name]
+        cnt = int(self._lib.psim_debug_size(self._ctx, name.encode()))
+        if cnt < 0:
+            raise KeyError(name)
+        out = np.empty((cnt,) + tail, dtype=dtype)
+        _capi.check(self._lib, self._lib.psim_debug_fetch(self._ctx, name.encode(),
+                                                          out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        return out
+
+    def canonical_tree(self):
+        """The tree in the order-independent form the golden fixtures use:
+        internal nodes as (depth, path) sorted, with mass and COM; occupied leaves
+        as (depth, path, particle) sorted by particle."""
+        key = self.debug_array("key")
+        perm = self.debug_array("perm")
+        L = self.debug_array("L").astype(np.int64)
+        rec = self.debug_array("rec")
+        first = self.debug_array("node_first").astype(np.int64)
+        depth = self.debug_array("node_depth").astype(np.int64)
+        n = len(key)
+        m = len(first)
+        ids = np.arange(m, dtype=np.int64)
+        r = rec[first + ids] if m else rec[:0]
+        shift = (64 - 2 * depth).astype(np.uint64)
+        path = np.where(depth > 0, key[first] >> np.minimum(shift, np.uint64(63)), np.uint64(0)) if m else np.zeros(0, np.uint64)
+        order = np.lexsort((path, depth)) if m else np.zeros(0, np.int64)
+        # leaf depth = 1 + deepest internal ancestor = 1 + max shared levels with a neighbour
+        lp = np.concatenate(([-1], L[:-1])) if n else L
+        ld = (np.maximum(L, lp) + 1) if n > 1 else np.zeros(n, np.int64)
+        lshift = (64 - 2 * ld).astype(np.uint64)
+        lpath = np.where(ld > 0, np.where(lshift >= 64, np.uint64(0), key >> np.minimum(lshift, np.uint64(63))), np.uint64(0))
+        lorder = np.argsort(perm, kind="stable")
+        return dict(
+            tree_nodes=(1 + 4 * m) if n else 0, tree_max_depth=int(ld.max()) if n else 0,
+            int_depth=depth[order].astype(np.int32), int_path=path[order].astype(np.uint64),
+            int_mass=r["mass"][order], int_comx=r["x"][order], int_comy=r["y"][order],
+            leaf_depth=ld[lorder].astype(np.int32), leaf_path=lpath[lorder].astype(np.uint64),
+            leaf_particle=perm[lorder].astype(np.int32))
+
+    # ------------------------------------------------------------------ rendering (main.py:95,106)
+    def draw(self, screen, is_glow_pass: bool):
+        """particle_system.py:587-624: one filled circle per particle, coloured by
+        temperature through the keyframe ramp of constants.py:37-45."""
+        import pygame
+        pos, temps, radii = self.positions, self.temperatures, self.radii
+        sane = np.nan_to_num(temps[:, 0], nan=constants.COLOR_MIN_TEMP, posinf=constants.COLOR_MAX_TEMP,
+                             neginf=constants.COLOR_MIN_TEMP)
+        t = np.clip((sane - constants.COLOR_MIN_TEMP) / (constants.COLOR_MAX_TEMP - constants.COLOR_MIN_TEMP), 0, 1)
+        rgb = constants.ramp_colors(t)
+        for i in range(self.num_particles):
+            c = (int(rgb[i, 0]), int(rgb[i, 1]), int(rgb[i, 2]))
+            if is_glow_pass:
+                c = c + (255,)
+            pygame.draw.circle(screen, c, (int(pos[i, 0]), int(pos[i, 1])), int(radii[i, 0]))
+
+
+def _make_property(name):
+    def getter(self):
+        self._refresh()
+        return self._host[name]
+
+    def setter(self, value):
+        self._refresh()
+        self._host[name] = np.ascontiguousarray(value)
+    return property(getter, setter)
+
+
+for _name in _FIELDS:
+    setattr(ParticleSystem, _name, _make_property(_name))

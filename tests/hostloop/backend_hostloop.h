@@ -1,0 +1,95 @@
+// TEST-ONLY back end: runs the per-element kernel bodies of
+// particle-simulator_amd/csrc/psim_kernels.h as plain host loops, with
+// std::stable_sort / sequential scan standing in for the cooperative HIP
+// primitives.  It exists so the step's host orchestration and kernel-body logic
+// can be exercised by the CPU test-suite on a machine without a GPU.  It is
+// never built into, loaded by, or a fallback for the product library.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+#include <vector>
+#include "psim_types.h"
+
+namespace psim {
+namespace be {
+
+typedef int Stream;
+
+inline void* dev_alloc(size_t bytes) { return calloc(bytes ? bytes : 16, 1); }
+inline void dev_free(void* p) { free(p); }
+inline void dev_memset(Stream, void* p, int v, size_t bytes) { if (bytes) memset(p, v, bytes); }
+inline void copy_h2d(Stream, void* d, const void* h, size_t bytes) { if (bytes) memcpy(d, h, bytes); }
+inline void copy_d2h(Stream, void* h, const void* d, size_t bytes) { if (bytes) memcpy(h, d, bytes); }
+inline void copy_d2d(Stream, void* d, const void* s, size_t bytes) { if (bytes) memmove(d, s, bytes); }
+inline void sync(Stream) {}
+
+template <class F>
+inline void launch(Stream, int64_t n, const F& f)
+{
+    for (int64_t i = 0; i < n; ++i) f(i);
+}
+
+inline size_t scan_temp_words(uint64_t) { return 1; }
+inline void exclusive_scan_u32(Stream, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t*, uint32_t* total_out)
+{
+    uint32_t run = 0;
+    for (uint64_t i = 0; i < n; ++i) { uint32_t t = in[i]; out[i] = run; run += t; }
+    if (total_out) *total_out = run;
+}
+
+inline size_t sort_temp_words(uint64_t) { return 1; }
+template <class KeyT>
+inline int radix_sort_pairs(Stream, KeyT* k[2], uint32_t* v[2], uint64_t n, int bit_lo, int bit_hi, uint32_t*)
+{
+    if (n <= 1) return 0;
+    int passes = (bit_hi - bit_lo + 7) / 8;
+    int top = bit_lo + 8 * passes;
+    KeyT mask = (top >= (int)(8 * sizeof(KeyT))) ? ~(KeyT)0 : (((KeyT)1 << top) - 1);
+    mask &= ~(((KeyT)1 << bit_lo) - 1);
+    std::vector<uint64_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    const KeyT* kk = k[0];
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint64_t a, uint64_t b) { return (kk[a] & mask) < (kk[b] & mask); });
+    int dst = passes & 1;      // same parity as the HIP pass loop
+    std::vector<KeyT> ko(n);
+    std::vector<uint32_t> vo(n);
+    for (uint64_t i = 0; i < n; ++i) { ko[i] = k[0][order[i]]; if (v) vo[i] = v[0][order[i]]; }
+    memcpy(k[dst], ko.data(), n * sizeof(KeyT));
+    if (v) memcpy(v[dst], vo.data(), n * sizeof(uint32_t));
+    return dst;
+}
+
+constexpr int kReduceBlocks = 1024;
+inline void reduce_sum_f64(Stream, const double* in, uint64_t n, double*, double* out)
+{
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; ++i) s += in[i];
+    *out = s;
+}
+
+}  // namespace be
+}  // namespace psim
+
+#include <chrono>
+namespace psim {
+namespace be {
+struct StageTimer {
+    static constexpr int kMarks = 9;
+    std::chrono::steady_clock::time_point t[kMarks];
+    bool complete = false;
+    void init() {}
+    void destroy() {}
+    void mark(Stream, int i) { t[i] = std::chrono::steady_clock::now(); if (i == kMarks - 1) complete = true; }
+    void read(double* ms)
+    {
+        for (int i = 0; i < kMarks - 1; ++i)
+            ms[i] = complete ? std::chrono::duration<double, std::milli>(t[i + 1] - t[i]).count() : 0.0;
+    }
+};
+}  // namespace be
+}  // namespace psim

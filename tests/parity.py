@@ -1,0 +1,130 @@
+"""Shared parity checks: a `ParticleSystem` of this build (bound to whichever
+library the caller names) against the golden fixtures recorded from the
+reference and against the C oracle.
+
+Bars (north star): Morton keys / tree topology / grid / contact pair lists
+bit-exact; COM and per-contact energies bit-exact while the state feeding them
+is bit-exact; accelerations, positions, velocities, temperatures within the
+relative tolerance written at each assert (the reference's gravity, conduction
+and PE kernels are `fastmath`, so they have no bit-level definition)."""
+import numpy as np
+
+from conftest import load_golden
+from psim_amd.particle_system import ParticleSystem
+
+TREE_KEYS_EXACT = ["int_depth", "int_path", "leaf_depth", "leaf_path", "leaf_particle"]
+TREE_KEYS_COM = ["int_mass", "int_comx", "int_comy"]
+
+# relative tolerance on accelerations: FP64 walk, summation order differs from the
+# reference's recursion (whose own result is only defined up to reassociation)
+ACC_RTOL = 2e-12
+
+
+def make_system(g, library, walk_mode=0, debug=True, **kw):
+    s = ParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds, library=library, walk_mode=walk_mode,
+                       debug=debug, **kw)
+    v = g.init_velocities()
+    if v is not None:
+        s.velocities[:] = v
+        s.push_state()
+    return s
+
+
+def check_tree(s, g, prefix, com_exact=True):
+    ct = s.canonical_tree()
+    assert ct["tree_nodes"] == int(g[prefix + "tree_nodes"]), prefix
+    for k in TREE_KEYS_EXACT:
+        np.testing.assert_array_equal(ct[k], g[prefix + k], err_msg=prefix + k)
+    for k in TREE_KEYS_COM:
+        if com_exact:
+            np.testing.assert_array_equal(ct[k], g[prefix + k], err_msg=prefix + k)
+        else:
+            np.testing.assert_allclose(ct[k], g[prefix + k], rtol=1e-11, err_msg=prefix + k)
+
+
+def acc_close(got, want, rtol=ACC_RTOL):
+    scale = np.abs(want).max() if want.size else 1.0
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * scale * 1e-3)
+
+
+def run_golden_stepwise(name, library, walk_mode=0):
+    """Prime + every recorded step of one fixture, checking each stage output."""
+    g = load_golden(name)
+    s = make_system(g, library, walk_mode)
+    np.testing.assert_array_equal(s.positions, g["init_positions"])
+    np.testing.assert_array_equal(s.radii, g["init_radii"])
+    s._calculate_gravity()
+    check_tree(s, g, "init_")
+    acc_close(s.accelerations, g["prime_accelerations"])
+    np.testing.assert_allclose(s.get_energies(), g["prime_energies"], rtol=1e-11)
+    exact = True            # state still bit-identical to the reference's
+    for step in range(1, g.steps + 1):
+        s.update()
+        p = "s%d_" % step
+        cand, ncont, nodes, n_after, n_expl = (int(x) for x in g["counts"][step - 1])
+        c = s.counts()
+        assert c["particles"] == n_after, (step, "n")
+        assert c["tree_nodes"] == nodes, (step, "nodes")
+        assert c["contacts"] == ncont, (step, "contacts")
+        assert c["candidates"] == cand, (step, "candidates")
+        assert c["exploded"] == n_expl, (step, "exploded")
+        if (p + "grid_offsets") not in g:
+            continue
+        # grid + tree are built from post-drift positions: exact while the state is
+        np.testing.assert_array_equal(s.debug_array("grid_offsets"), g[p + "grid_offsets"])
+        np.testing.assert_array_equal(s.debug_array("grid_indices"), g[p + "grid_indices"])
+        check_tree(s, g, p, com_exact=False)
+        ij = s.debug_array("contact_ij")
+        np.testing.assert_array_equal(ij, g[p + "contact_ij"], err_msg="step %d contact pair list" % step)
+        np.testing.assert_allclose(s.debug_array("contact_vals"), g[p + "contact_vals"], rtol=1e-7, atol=1e-13)
+        np.testing.assert_array_equal(s.debug_array("exploded"), g[p + "exploded"])
+        d = np.zeros(len(g[p + "delta_temps"]))
+        dd = s.debug_array("delta_temps")
+        d[:len(dd)] = dd
+        np.testing.assert_allclose(d, g[p + "delta_temps"].ravel(), rtol=1e-9, atol=1e-16)
+        np.testing.assert_allclose(s.positions, g[p + "positions"], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(s.velocities, g[p + "velocities"], rtol=1e-9, atol=1e-13)
+        acc_close(s.accelerations, g[p + "accelerations"], rtol=1e-10)
+        np.testing.assert_allclose(s.temperatures, g[p + "temperatures"], rtol=1e-10, atol=1e-15)
+        np.testing.assert_allclose(s.get_energies(), g["energies"][step - 1], rtol=1e-9)
+        tot = np.array([s.pe_gain_collisions, s.ke_loss_collisions, s.heat_generated_collisions])
+        np.testing.assert_allclose(tot, g["collision_totals"][step - 1], rtol=1e-7, atol=1e-12)
+    s.close()
+
+
+def run_against_oracle(n, sim, seed, bounds, steps, library, walk_mode=0, state=None, stage_mask=31,
+                       check_contacts=True):
+    """Same seeded inputs through this build and through the C oracle."""
+    from oracle.oracle import OracleSystem
+    rng_a, rng_b = np.random.default_rng(seed), np.random.default_rng(seed)
+    o = OracleSystem(n, sim, rng_a, bounds, state=state, stage_mask=stage_mask)
+    s = ParticleSystem(n, dict(sim), rng_b, bounds, library=library, walk_mode=walk_mode, debug=True,
+                       state=state, stage_mask=stage_mask)
+    o.enable_contact_log(1 << 22)
+    o._calculate_gravity()
+    s._calculate_gravity()
+    assert s.counts()["tree_nodes"] == o.num_active_nodes
+    acc_close(s.accelerations, o.accelerations)
+    for step in range(1, steps + 1):
+        o.update()
+        s.update()
+        c = s.counts()
+        assert c["particles"] == o.num_particles, step
+        assert c["tree_nodes"] == o.num_active_nodes, step
+        if stage_mask & 1:
+            assert c["contacts"] == o.n_contacts, step
+            assert c["candidates"] == o.n_candidates, step
+            if check_contacts:
+                ij, vals = o.contact_log()
+                np.testing.assert_array_equal(s.debug_array("contact_ij"), ij, err_msg="step %d" % step)
+        np.testing.assert_array_equal(s.debug_array("grid_offsets"), o.grid_offsets)
+        np.testing.assert_array_equal(s.debug_array("grid_indices"), o.grid_indices)
+        np.testing.assert_array_equal(s.debug_array("exploded"), o.exploded)
+        np.testing.assert_allclose(s.positions, o.positions, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(s.velocities, o.velocities, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(s.temperatures, o.temperatures, rtol=1e-9, atol=1e-15)
+    e_s = np.array(s.get_energies())
+    e_o = np.array([o.get_total_kinetic_energy(), o.get_total_potential_energy(), o.get_total_thermal_energy()])
+    np.testing.assert_allclose(e_s, e_o, rtol=1e-8)
+    s.close()
+    return s, o

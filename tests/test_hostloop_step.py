@@ -1,0 +1,39 @@
+"""CPU checks of the step's host orchestration and per-element kernel bodies:
+the same sources as the HIP library, compiled by tests/hostloop/Makefile into a
+test-only host-loop build (each kernel body runs as a plain for loop), checked
+stage by stage against the golden fixtures and the C oracle.  The cooperative
+HIP primitives (radix sort, scan, reduction, wave-cooperative walk) are NOT
+covered here -- they only exist on the GPU and are covered by the gpu tests."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import parity
+
+HOSTLOOP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostloop")
+HOSTLOOP = os.path.join(HOSTLOOP_DIR, "libpsim_hostloop.so")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def build_hostloop():
+    subprocess.check_call(["make", "-s", "-C", HOSTLOOP_DIR])
+
+
+@pytest.mark.parametrize("name", ["tiny64", "dense256", "dense400", "hot300", "fast200"])
+def test_golden_stepwise(name):
+    parity.run_golden_stepwise(name, HOSTLOOP, walk_mode=1)
+
+
+def test_default_run_first_steps():
+    parity.run_golden_stepwise("default2000", HOSTLOOP, walk_mode=1)
+
+
+def test_tree_gravity_20k():
+    g = parity.load_golden("tree20k")
+    s = parity.make_system(g, HOSTLOOP, walk_mode=1)
+    s._calculate_gravity()
+    parity.check_tree(s, g, "init_")
+    parity.acc_close(s.accelerations, g["prime_accelerations"])
+    np.testing.assert_allclose(s.get_energies()[1], g["prime_energies"][1], rtol=1e-11)
