@@ -404,7 +404,8 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
             }
         }
         const bool open = active && !take && !leaf;
-        j = (__ballot(open) != 0ull) ? ju + 1u : r.skip;
+        const uint32_t nxt = (__ballot(open) != 0ull) ? ju + 1u : r.skip;
+        j = nxt > ju ? nxt : ju + 1u;      // cursor is strictly monotonic whatever the array holds
     }
     if (live) {
         uint32_t p = perm[s];

@@ -362,7 +362,7 @@ struct GravityWalkSimple {
                 ax += f * dx;
                 ay += f * dy;
                 ++inter;
-                j = r.skip;
+                j = r.skip > j ? r.skip : j + 1;
             } else {
                 j = j + 1;
             }
