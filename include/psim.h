@@ -119,8 +119,10 @@ typedef struct psim_explosion_event {
 int64_t psim_explosion_events(psim_context* ctx, psim_explosion_event* buf, int64_t cap);
 
 /* gravity work counters: runs one counted walk over the current tree and returns
- * node visits and accepted interactions summed over particles */
-int psim_walk_counts(psim_context* ctx, int64_t out[2]);
+ * [0] node visits and [1] accepted interactions summed over particles (the
+ * reference's own per-particle recursion makes exactly these), [2] loop trips
+ * summed over 64-lane waves, [3] trips in which some lane accepted */
+int psim_walk_counts(psim_context* ctx, int64_t out[4]);
 
 /* parity hooks: copy a named internal device array to the host.
  * psim_debug_size returns the element count (or < 0 for an unknown name);

@@ -161,6 +161,23 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, uin
     }
 }
 
+// whole scan in one 1024-lane workgroup (n <= 1024 * kScanItems): one launch instead of three
+__global__ void __launch_bounds__(1024) scan_small_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
+                                                          uint32_t* total_out)
+{
+    __shared__ uint32_t wsum[17];
+    uint32_t base = threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+    uint32_t total;
+    uint32_t ex = block_exclusive_scan(s, wsum, &total);
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+    if (threadIdx.x == 0 && total_out) *total_out = total;
+}
+
 inline size_t scan_temp_words(uint64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile) + 1; }
 
 // out may alias in.  temp: scan_temp_words(n) words.  total_out: device word or null.
@@ -169,6 +186,11 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
 {
     if (n == 0) { if (total_out) dev_memset(st, total_out, 0, 4); return; }
     if (n > 0xfffffff0ull) throw std::runtime_error("exclusive_scan_u32: too many items");
+    if (n <= 1024u * kScanItems) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, out, (uint32_t)n, total_out);
+        PSIM_HIP(hipGetLastError());
+        return;
+    }
     uint32_t nb = (uint32_t)((n + kScanTile - 1) / kScanTile);
     if (nb > 1024u * 64u) throw std::runtime_error("exclusive_scan_u32: spine too long");
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, st, in, (uint32_t)n, temp);
@@ -362,18 +384,22 @@ inline void reduce_sum_f64(Stream st, const double* in, uint64_t n, double* temp
 namespace psim {
 namespace be {
 
+// 1/sqrt(x): the hardware estimate (v_rsq_f64, about 2^-29 relative) plus one
+// Newton step, y (1 + e/2) with e = 1 - x y^2: about 2^-56 relative.
 __device__ __forceinline__ double rsqrt_refined(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-(x * y), y, 1.0);                 // 1 - x y^2
-    return fma(y * e, fma(0.375, e, 0.5), y);         // y (1 + e/2 + 3 e^2 / 8)
+    double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, 0.5, y);
 }
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     int64_t n, const NodeRec* __restrict__ rec, uint32_t total_elems, const vec2* __restrict__ spos,
     const double* __restrict__ smass, const uint32_t* __restrict__ perm, const double* __restrict__ inv_mass,
-    vec2* __restrict__ acc_out, const double* __restrict__ w2tab, double theta2, double g_const, double softening,
+    vec2* __restrict__ acc_out, double w2_root, double theta2, double g_const, double softening,
     unsigned long long* __restrict__ counters)
 {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -382,30 +408,48 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     if (live) { vec2 p = spos[s]; px = p.x; py = p.y; }
     uint32_t until = live ? 0u : 0xffffffffu;
     double ax = 0.0, ay = 0.0;
-    uint32_t visits = 0, inter = 0;
-    uint32_t j = 0;
-    while (j < total_elems) {
-        const uint32_t ju = __builtin_amdgcn_readfirstlane(j);
-        const NodeRec r = rec[ju];
-        const bool leaf = r.depth == kLeaf;
-        const double w2 = leaf ? -1.0 : w2tab[leaf ? 0u : r.depth];
+    uint32_t visits = 0, inter = 0, trips = 0, force_trips = 0;
+    // squared node width of depth d = w2_root * 4^-d: subtract 2d from the exponent field
+    const uint64_t w2_bits = (uint64_t)__double_as_longlong(w2_root);
+    const double4_t* __restrict__ rec4 = reinterpret_cast<const double4_t*>(rec);
+    uint32_t ju = 0;
+    while (ju < total_elems) {
+        // one 32-byte scalar fetch per element: {mass, x, y, skip | depth << 32}
+        const double4_t rv = rec4[ju];
+        const uint64_t meta = (uint64_t)__double_as_longlong(rv.w);
+        const uint32_t skip = (uint32_t)meta, depth = (uint32_t)(meta >> 32);
+        const uint32_t ja = ju + 1u;
+        const uint32_t jb = skip > ju ? skip : ja;           // strictly monotonic whatever the array holds
+        const bool leaf = depth == kLeaf;
+        // internal: accept iff w^2 < theta^2 d^2 (which implies d^2 > 0 since w^2 > 0);
+        // leaf: interact iff 0 < d^2.  One compare serves both: lhs < scale * d^2.
+        const double lhs = leaf ? 0.0 : __longlong_as_double((long long)(w2_bits - ((uint64_t)(depth & 31u) << 53)));
+        const double scale = leaf ? 1.0 : theta2;
         const bool active = until <= ju;
-        const double dx = r.x - px, dy = r.y - py;
+        const double dx = rv.y - px, dy = rv.z - py;
         const double d2 = fma(dx, dx, dy * dy);
-        const bool take = active && d2 > 0.0 && w2 < theta2 * d2;
-        if (COUNT) { visits += active ? 1u : 0u; inter += take ? 1u : 0u; }
-        if (__ballot(take) != 0ull) {
-            if (take) {
-                double ri = rsqrt_refined(d2 + softening);
-                double f = r.mass * (ri * ri * ri);
-                ax = fma(f, dx, ax);
-                ay = fma(f, dy, ay);
-                until = r.skip;
+        const bool take = active && (lhs < scale * d2);
+        if (COUNT) {
+            const unsigned long long take_mask = __builtin_amdgcn_ballot_w64(take);
+            visits += active ? 1u : 0u; inter += take ? 1u : 0u; trips += 1u; force_trips += take_mask ? 1u : 0u;
+            const int pc = __popcll(take_mask);
+            const int pa = __popcll(__builtin_amdgcn_ballot_w64(active));
+            if ((threadIdx.x & 63) == 0) {
+                int b = pc == 0 ? 0 : pc <= 8 ? 1 : pc <= 16 ? 2 : pc <= 32 ? 3 : pc < 64 ? 4 : 5;
+                int ba = pa == 0 ? 0 : pa <= 8 ? 1 : pa <= 16 ? 2 : pa <= 32 ? 3 : pa < 64 ? 4 : 5;
+                atomicAdd(&counters[4 + (leaf ? 6 : 0) + b], 1ull);
+                atomicAdd(&counters[16 + (leaf ? 6 : 0) + ba], 1ull);
             }
         }
+        if (take) {                                          // skipped as a whole when no lane accepts
+            double ri = rsqrt_refined(d2 + softening);
+            double f = (rv.x * ri) * (ri * ri);
+            ax = fma(f, dx, ax);
+            ay = fma(f, dy, ay);
+            until = jb;
+        }
         const bool open = active && !take && !leaf;
-        const uint32_t nxt = (__ballot(open) != 0ull) ? ju + 1u : r.skip;
-        j = nxt > ju ? nxt : ju + 1u;      // cursor is strictly monotonic whatever the array holds
+        ju = (__builtin_amdgcn_ballot_w64(open) != 0ull) ? ja : jb;
     }
     if (live) {
         uint32_t p = perm[s];
@@ -419,6 +463,10 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)visits);
         atomicAdd(&counters[1], (unsigned long long)inter);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&counters[2], (unsigned long long)trips);
+            atomicAdd(&counters[3], (unsigned long long)force_trips);
+        }
     }
 }
 

@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <random>
+#include <stdio.h>
+#include <stdlib.h>
 
 static_assert(sizeof(psim_config) == sizeof(psim::Config), "psim_config and psim::Config must match");
 static_assert(sizeof(psim_explosion_event) == sizeof(psim::ExplosionEvent), "event layout");
@@ -25,10 +27,11 @@ void Sim::gravity(vec2* out)
 #if !defined(PSIM_HOSTLOOP)
     if (cfg.walk_mode == 0) {
         int64_t blocks = (n + 255) / 256;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(be::gravity_walk_wave_kernel<false>), dim3((unsigned)blocks), dim3(256), 0,
+        auto kern = be::gravity_walk_wave_kernel<false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0,
                            st, n, (const NodeRec*)rec.p, total, (const vec2*)spos.p, (const double*)smass.p,
                            (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p, out,
-                           (const double*)w2tab.p, theta2, cfg.gravity_constant, cfg.softening,
+                           cfg.bounds_w * cfg.bounds_w, theta2, cfg.gravity_constant, cfg.softening,
                            (unsigned long long*)nullptr);
         PSIM_HIP(hipGetLastError());
         return;
@@ -206,11 +209,11 @@ int64_t psim_explosion_events(psim_context* ctx, psim_explosion_event* buf, int6
     return k;
 }
 
-static void walk_counts_impl(psim_context* ctx, int64_t out[2])
+static void walk_counts_impl(psim_context* ctx, int64_t out[4])
 {
     use_device(ctx->device);
     psim::Sim* s = ctx->sim;
-    out[0] = out[1] = 0;
+    out[0] = out[1] = out[2] = out[3] = 0;
     if (!s->tree_valid || s->n == 0) throw std::runtime_error("psim: no tree built yet");
     uint32_t total = (uint32_t)(s->n + s->n_internal);
     double theta2 = s->cfg.theta * s->cfg.theta;
@@ -218,20 +221,29 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[2])
     scratch.ensure((size_t)s->n);
 #if !defined(PSIM_HOSTLOOP)
     psim::DevBuf<unsigned long long> cnt;
-    cnt.ensure(2);
-    psim::be::dev_memset(s->st, cnt.p, 0, 16);
+    cnt.ensure(32);
+    psim::be::dev_memset(s->st, cnt.p, 0, 256);
     int64_t blocks = (s->n + 255) / 256;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(psim::be::gravity_walk_wave_kernel<true>), dim3((unsigned)blocks), dim3(256), 0,
                        s->st, s->n, (const psim::NodeRec*)s->rec.p, total, (const psim::vec2*)s->spos.p,
                        (const double*)s->smass.p, (const uint32_t*)s->perm[s->sorted_key].p,
-                       (const double*)s->inv_mass.p, scratch.p, (const double*)s->w2tab.p, theta2,
+                       (const double*)s->inv_mass.p, scratch.p, s->cfg.bounds_w * s->cfg.bounds_w, theta2,
                        s->cfg.gravity_constant, s->cfg.softening, cnt.p);
     PSIM_HIP(hipGetLastError());
-    unsigned long long h[2];
-    psim::be::copy_d2h(s->st, h, cnt.p, 16);
+    unsigned long long h[32];
+    psim::be::copy_d2h(s->st, h, cnt.p, 256);
     psim::be::sync(s->st);
+    if (getenv("PSIM_WALK_HIST")) {
+        const char* names[4] = {"take/internal", "take/leaf", "active/internal", "active/leaf"};
+        for (int g = 0; g < 4; ++g) {
+            fprintf(stderr, "walk hist %-16s lanes 0:%llu 1-8:%llu 9-16:%llu 17-32:%llu 33-63:%llu 64:%llu\n", names[g],
+                    h[4 + 6 * g], h[5 + 6 * g], h[6 + 6 * g], h[7 + 6 * g], h[8 + 6 * g], h[9 + 6 * g]);
+        }
+    }
     out[0] = (int64_t)h[0];
     out[1] = (int64_t)h[1];
+    out[2] = (int64_t)h[2];
+    out[3] = (int64_t)h[3];
 #else
     psim::DevBuf<uint32_t> cnt;
     cnt.ensure(2);
@@ -243,10 +255,11 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[2])
     psim::be::launch(s->st, s->n, k);
     out[0] = cnt.p[0];
     out[1] = cnt.p[1];
+    out[2] = out[3] = 0;
 #endif
 }
 
-int psim_walk_counts(psim_context* ctx, int64_t out[2])
+int psim_walk_counts(psim_context* ctx, int64_t out[4])
 {
     PSIM_TRY(ctx && out, walk_counts_impl(ctx, out))
 }

@@ -23,6 +23,19 @@ __device__ __forceinline__ uint32_t atomic_inc_u32(uint32_t* p, uint32_t v) { re
 __device__ __forceinline__ int clz64(uint64_t x) { return x ? __clzll((long long)x) : 64; }
 #endif
 
+// add 1 to *p for every calling lane; one atomic per wave (the lanes that reach
+// this call together are counted by ballot and the first of them adds the sum)
+#if defined(PSIM_HOSTLOOP)
+inline void aggregated_inc(uint32_t* p) { *p += 1; }
+#else
+__device__ __forceinline__ void aggregated_inc(uint32_t* p)
+{
+    unsigned long long m = __ballot(1);
+    int lane = (int)(threadIdx.x & 63u);
+    if (lane == __ffsll((long long)m) - 1) atomicAdd(p, (uint32_t)__popcll(m));
+}
+#endif
+
 // quadtree.py:13-19 (_get_quadrant) + :24-38,62-63 (child boxes, centre = x + w/2):
 // descend 32 levels from the root box exactly as an insertion would, recording
 // quadrant = 2*(y >= cy) + (x >= cx) per level, most significant first.
@@ -113,19 +126,38 @@ struct SegmentOffsets {
     }
 };
 
-// cell-sorted ("slot space") copies used by the neighbour sweeps
+// largest cell population (run over cells): lanes only issue an atomic when they
+// would raise the value they just read
+struct MaxOccupancy {
+    int64_t cells;
+    const int32_t* offsets;
+    uint32_t* out;
+    PSIM_HD void operator()(int64_t c) const
+    {
+        uint32_t occ = (uint32_t)(offsets[c + 1] - offsets[c]);
+#if defined(PSIM_HOSTLOOP)
+        if (occ > *out) *out = occ;
+#else
+        if (occ > *((volatile uint32_t*)out)) atomicMax(out, occ);
+#endif
+    }
+};
+
+// cell-sorted ("slot space") records used by the neighbour sweeps
 struct GatherCell {
     int64_t n;
     const uint32_t* cperm;
+    const uint32_t* ckey;
     const vec2* pos;
     const int32_t* radii;
-    vec2* cpos;
-    int32_t* crad;
+    CellBody* body;
     PSIM_HD void operator()(int64_t k) const
     {
         uint32_t p = cperm[k];
-        cpos[k] = pos[p];
-        crad[k] = radii[p];
+        vec2 P = pos[p];
+        CellBody b;
+        b.x = P.x; b.y = P.y; b.r = radii[p]; b.idx = p; b.cell = ckey[k]; b.pad = 0;
+        body[k] = b;
     }
 };
 
@@ -404,15 +436,18 @@ struct Kick {
 // pair_key packs that order into one integer; a pair is always keyed from its
 // lower-index particle, whose cell is the home cell.
 struct GridView {
-    const uint32_t* cperm;     // slot -> particle index (grid_indices)
-    const uint32_t* ckey;      // slot -> cell
+    const CellBody* body;      // slot -> {position, radius, particle index (grid_indices), cell}
     const int32_t* offsets;    // cell -> first slot
     int32_t gw, gh;
+    int32_t slot_bits;         // bits of the in-cell position fields of a pair key (>= bits of max occupancy)
 };
 
-PSIM_HD PSIM_FORCEINLINE uint64_t make_pair_key(uint32_t cell, uint32_t phase, uint32_t a, uint32_t b)
+// key = cell | phase:4 | a:slot_bits | b:slot_bits, packed tightly so that the
+// radix sorts of contact lists run as few digit passes as the grid allows
+PSIM_HD PSIM_FORCEINLINE uint64_t make_pair_key(const GridView& g, uint32_t cell, uint32_t phase, uint32_t a, uint32_t b)
 {
-    return ((uint64_t)cell << 40) | ((uint64_t)phase << 36) | ((uint64_t)a << kSlotBits) | (uint64_t)b;
+    int sb = g.slot_bits;
+    return ((((((uint64_t)cell << 4) | (uint64_t)phase) << sb) | (uint64_t)a) << sb) | (uint64_t)b;
 }
 
 PSIM_HD PSIM_FORCEINLINE uint32_t neighbour_phase(int dy, int dx) { return 1u + (uint32_t)((dy + 1) * 3 + (dx + 1)); }
@@ -420,8 +455,8 @@ PSIM_HD PSIM_FORCEINLINE uint32_t neighbour_phase(int dy, int dx) { return 1u + 
 PSIM_HD PSIM_FORCEINLINE uint64_t pair_key(const GridView& g, uint32_t sx, uint32_t sy)
 {
     uint32_t lo = sx, hi = sy;
-    if (g.cperm[sy] < g.cperm[sx]) { lo = sy; hi = sx; }
-    uint32_t cl = g.ckey[lo], ch = g.ckey[hi];
+    if (g.body[sy].idx < g.body[sx].idx) { lo = sy; hi = sx; }
+    uint32_t cl = g.body[lo].cell, ch = g.body[hi].cell;
     uint32_t a = lo - (uint32_t)g.offsets[cl], b = hi - (uint32_t)g.offsets[ch];
     uint32_t phase = 0;
     if (cl != ch) {
@@ -429,14 +464,16 @@ PSIM_HD PSIM_FORCEINLINE uint64_t pair_key(const GridView& g, uint32_t sx, uint3
         int dy = (int)(ch / (uint32_t)g.gw) - (int)(cl / (uint32_t)g.gw);
         phase = neighbour_phase(dy, dx);
     }
-    return make_pair_key(cl, phase, a, b);
+    return make_pair_key(g, cl, phase, a, b);
 }
 
 PSIM_HD PSIM_FORCEINLINE void decode_pair_key(const GridView& g, uint64_t key, uint32_t* si, uint32_t* sj)
 {
-    uint32_t cell = (uint32_t)(key >> 40);
-    uint32_t phase = (uint32_t)(key >> 36) & 15u;
-    uint32_t a = (uint32_t)(key >> kSlotBits) & kSlotMask, b = (uint32_t)key & kSlotMask;
+    int sb = g.slot_bits;
+    uint32_t mask = (1u << sb) - 1u;
+    uint32_t b = (uint32_t)key & mask, a = (uint32_t)(key >> sb) & mask;
+    uint32_t phase = (uint32_t)(key >> (2 * sb)) & 15u;
+    uint32_t cell = (uint32_t)(key >> (2 * sb + 4));
     uint32_t nc = cell;
     if (phase) {
         int idx = (int)phase - 1;
@@ -455,12 +492,14 @@ PSIM_HD PSIM_FORCEINLINE bool in_contact(vec2 pi, vec2 pj, int32_t ri, int32_t r
     return d2 < (double)(md * md) && d2 > 0;
 }
 
+PSIM_HD PSIM_FORCEINLINE vec2 body_pos(const CellBody& b) { vec2 v; v.x = b.x; v.y = b.y; return v; }
+
 // Enumerate, for slot k, every slot y of the 3x3 cell neighbourhood (own cell
 // first, then neighbours in (dy, dx) order).  F(y, phase_from_k_to_y).
 template <class F>
 PSIM_HD PSIM_FORCEINLINE void for_each_neighbour_slot(const GridView& g, uint32_t k, F f)
 {
-    uint32_t c = g.ckey[k];
+    uint32_t c = g.body[k].cell;
     int cx = (int)(c % (uint32_t)g.gw), cy = (int)(c / (uint32_t)g.gw);
     for (int32_t b = g.offsets[c]; b < g.offsets[c + 1]; ++b)
         if ((uint32_t)b != k) f((uint32_t)b);
@@ -474,32 +513,56 @@ PSIM_HD PSIM_FORCEINLINE void for_each_neighbour_slot(const GridView& g, uint32_
         }
 }
 
+// The same enumeration restricted to one of the nine cells: which = 0 is the own
+// cell, 1..9 (skipping 5) the neighbour in (dy, dx) order.
+template <class F>
+PSIM_HD PSIM_FORCEINLINE void for_each_slot_in_cell(const GridView& g, uint32_t k, int which, F f)
+{
+    uint32_t c = g.body[k].cell;
+    if (which == 0) {
+        for (int32_t b = g.offsets[c]; b < g.offsets[c + 1]; ++b)
+            if ((uint32_t)b != k) f((uint32_t)b);
+        return;
+    }
+    int idx = which - 1;
+    if (idx == 4) return;
+    int cx = (int)(c % (uint32_t)g.gw), cy = (int)(c / (uint32_t)g.gw);
+    int nx = cx + (idx % 3 - 1), ny = cy + (idx / 3 - 1);
+    if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) return;
+    uint32_t nc = (uint32_t)(ny * g.gw + nx);
+    for (int32_t b = g.offsets[nc]; b < g.offsets[nc + 1]; ++b) f((uint32_t)b);
+}
+
 // Sweep 0: test every candidate pair against the sweep's initial positions and
-// append the keys of those in contact (unordered; sorted afterwards).
+// collect the keys of those in contact (unordered between lanes; sorted
+// afterwards).  Two passes around an exclusive scan instead of an atomic
+// cursor: pass 0 stores how many contacts each slot found as the lower-index
+// particle, pass 1 (only slots with a non-zero count redo their tests) writes the
+// keys at the scanned offsets.
 struct ContactDetect {
     int64_t n;
     GridView g;
-    const vec2* cpos;
-    const int32_t* crad;
-    uint64_t* out_keys;
-    uint32_t* counter;
-    uint32_t cap;
-    uint32_t* cand_counter;    // optional: number of candidate pairs
-    PSIM_HD void operator()(int64_t kk) const
+    uint32_t* counts;          // pass 0: written; pass 1: read
+    const uint32_t* offsets;   // pass 1: exclusive scan of counts
+    uint64_t* out_keys;        // pass 1
+    int32_t write_pass;
+    uint32_t* cand_counter;    // optional (pass 0): number of candidate pairs
+    template <bool WRITE>
+    PSIM_HD PSIM_FORCEINLINE void run(uint32_t k) const
     {
-        uint32_t k = (uint32_t)kk;
-        uint32_t p = g.cperm[k];
-        uint32_t c = g.ckey[k];
+        const CellBody me = g.body[k];
+        uint32_t p = me.idx, c = me.cell;
         uint32_t a = k - (uint32_t)g.offsets[c];
-        vec2 P = cpos[k];
-        int32_t rp = crad[k];
+        vec2 P = body_pos(me);
         int cx = (int)(c % (uint32_t)g.gw), cy = (int)(c / (uint32_t)g.gw);
-        uint32_t ncand = 0;
+        uint32_t ncand = 0, found = 0;
+        uint32_t at = WRITE ? offsets[k] : 0u;
         for (int32_t b = (int32_t)k + 1; b < g.offsets[c + 1]; ++b) {
+            const CellBody o = g.body[b];
             ++ncand;
-            if (in_contact(P, cpos[b], rp, crad[b])) {
-                uint32_t at = atomic_inc_u32(counter, 1);
-                if (at < cap) out_keys[at] = make_pair_key(c, 0, a, (uint32_t)b - (uint32_t)g.offsets[c]);
+            if (in_contact(P, body_pos(o), me.r, o.r)) {
+                if (WRITE) out_keys[at + found] = make_pair_key(g, c, 0, a, (uint32_t)b - (uint32_t)g.offsets[c]);
+                ++found;
             }
         }
         for (int dy = -1; dy <= 1; ++dy)
@@ -508,19 +571,30 @@ struct ContactDetect {
                 int nx = cx + dx, ny = cy + dy;
                 if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) continue;
                 uint32_t nc = (uint32_t)(ny * g.gw + nx);
-                int32_t o = g.offsets[nc];
-                for (int32_t b = o; b < g.offsets[nc + 1]; ++b) {
-                    if (g.cperm[b] > p) {
+                int32_t o0 = g.offsets[nc];
+                for (int32_t b = o0; b < g.offsets[nc + 1]; ++b) {
+                    const CellBody o = g.body[b];
+                    if (o.idx > p) {
                         ++ncand;
-                        if (in_contact(P, cpos[b], rp, crad[b])) {
-                            uint32_t at = atomic_inc_u32(counter, 1);
-                            if (at < cap)
-                                out_keys[at] = make_pair_key(c, neighbour_phase(dy, dx), a, (uint32_t)(b - o));
+                        if (in_contact(P, body_pos(o), me.r, o.r)) {
+                            if (WRITE) out_keys[at + found] = make_pair_key(g, c, neighbour_phase(dy, dx), a, (uint32_t)(b - o0));
+                            ++found;
                         }
                     }
                 }
             }
-        if (cand_counter && ncand) atomic_inc_u32(cand_counter, ncand);
+        if (!WRITE) {
+            counts[k] = found;
+            if (cand_counter && ncand) atomic_inc_u32(cand_counter, ncand);
+        }
+    }
+    PSIM_HD void operator()(int64_t kk) const
+    {
+        if (write_pass) {
+            if (counts[kk] != 0) run<true>((uint32_t)kk);
+        } else {
+            run<false>((uint32_t)kk);
+        }
     }
 };
 
@@ -623,9 +697,7 @@ struct ContactSimulate {
     double* vals;             // [3h]
     uint32_t* executed;
     // initial state
-    const uint32_t* cperm;
-    const vec2* cpos;
-    const int32_t* crad;
+    const CellBody* body;
     const vec2* vel;
     const double* temp;
     const double* mass;
@@ -634,8 +706,8 @@ struct ContactSimulate {
     {
         if (pr < 0) {
             BodyState s;
-            uint32_t p = cperm[slot];
-            s.pos = cpos[slot];
+            uint32_t p = body[slot].idx;
+            s.pos = body_pos(body[slot]);
             s.vel = vel[p];
             s.temp = temp[p];
             return s;
@@ -652,13 +724,13 @@ struct ContactSimulate {
         uint32_t si = hsi[h], sj = hsj[h];
         BodyState I = fetch(si, pi), J = fetch(sj, pj);
         double v[3];
-        resolve_pair(I, J, mass[cperm[si]], mass[cperm[sj]], crad[si], crad[sj], G, soft, restitution,
+        resolve_pair(I, J, mass[body[si].idx], mass[body[sj].idx], body[si].r, body[sj].r, G, soft, restitution,
                      pos_correct, v);
         out[2 * h] = I;
         out[2 * h + 1] = J;
         vals[3 * h] = v[0]; vals[3 * h + 1] = v[1]; vals[3 * h + 2] = v[2];
         done[h] = round;
-        atomic_inc_u32(executed, 1);
+        aggregated_inc(executed);
     }
 };
 
@@ -666,7 +738,7 @@ struct ContactSimulate {
 // output of its last hypothesised contact ordered before t, else the initial one
 PSIM_HD PSIM_FORCEINLINE vec2 versioned_pos(uint32_t slot, uint64_t t, const int32_t* cseg, const uint64_t* adj,
                                             int64_t n_adj, const uint64_t* hkeys, const uint32_t* hsi,
-                                            const BodyState* out, const vec2* cpos)
+                                            const BodyState* out, const CellBody* body)
 {
     int32_t e0 = cseg[slot];
     int64_t last = -1;
@@ -676,15 +748,17 @@ PSIM_HD PSIM_FORCEINLINE vec2 versioned_pos(uint32_t slot, uint64_t t, const int
             if (hkeys[h] < t) last = h; else break;
         }
     }
-    if (last < 0) return cpos[slot];
+    if (last < 0) return body_pos(body[slot]);
     int side = (hsi[last] == slot) ? 0 : 1;
     return out[2 * last + side].pos;
 }
 
 // Re-test, against the versioned positions, every candidate pair that involves
-// a slot touched by a hypothesised contact.  Runs over adjacency entries; only
-// the first entry of a slot's segment works.  A pair of two touched slots is
-// emitted once, by the slot whose particle index is lower.
+// a slot touched by a hypothesised contact.  Element index = adjacency entry *
+// 10 + cell selector (the nine cells of one touched slot are re-tested by
+// different lanes); only the first entry of a slot's segment works.  A pair of
+// two touched slots is emitted once, by the slot whose particle index is lower.
+// Two passes around a scan, like ContactDetect: counts[t] then keys at offsets[t].
 struct ContactRetest {
     int64_t n_adj;
     GridView g;
@@ -693,53 +767,60 @@ struct ContactRetest {
     const uint64_t* hkeys;
     const uint32_t* hsi;
     const BodyState* out;
-    const vec2* cpos;
-    const int32_t* crad;
+    uint32_t* counts;
+    const uint32_t* offsets;
     uint64_t* out_keys;
-    uint32_t* counter;
-    uint32_t cap;
-    PSIM_HD void operator()(int64_t e) const
+    int32_t write_pass;
+    PSIM_HD void operator()(int64_t t) const
     {
+        if (write_pass && counts[t] == 0) return;
+        int64_t e = t / 10;
+        int which = (int)(t - e * 10);
         uint32_t x = (uint32_t)(adj[e] >> 32);
-        if (cseg[x] != (int32_t)e) return;
-        uint32_t px = g.cperm[x];
-        int32_t rx = crad[x];
-        const ContactRetest* self = this;
-        for_each_neighbour_slot(g, x, [=](uint32_t y) {
-            uint32_t py = self->g.cperm[y];
-            if (self->cseg[y] >= 0 && py < px) return;       // y's own pass emits it
-            uint64_t t = pair_key(self->g, x, y);
-            vec2 X = versioned_pos(x, t, self->cseg, self->adj, self->n_adj, self->hkeys, self->hsi,
-                                   self->out, self->cpos);
-            vec2 Y = versioned_pos(y, t, self->cseg, self->adj, self->n_adj, self->hkeys, self->hsi,
-                                   self->out, self->cpos);
-            bool hit = (px < py) ? in_contact(X, Y, rx, self->crad[y]) : in_contact(Y, X, self->crad[y], rx);
-            if (hit) {
-                uint32_t at = atomic_inc_u32(self->counter, 1);
-                if (at < self->cap) self->out_keys[at] = t;
-            }
-        });
+        uint32_t found = 0;
+        if (cseg[x] == (int32_t)e) {
+            uint32_t px = g.body[x].idx;
+            int32_t rx = g.body[x].r;
+            uint32_t at = write_pass ? offsets[t] : 0u;
+            for_each_slot_in_cell(g, x, which, [&](uint32_t y) {
+                uint32_t py = g.body[y].idx;
+                int32_t ry = g.body[y].r;
+                if (cseg[y] >= 0 && py < px) return;       // y's own pass emits it
+                uint64_t tk = pair_key(g, x, y);
+                vec2 X = versioned_pos(x, tk, cseg, adj, n_adj, hkeys, hsi, out, g.body);
+                vec2 Y = versioned_pos(y, tk, cseg, adj, n_adj, hkeys, hsi, out, g.body);
+                bool hit = (px < py) ? in_contact(X, Y, rx, ry) : in_contact(Y, X, ry, rx);
+                if (hit) {
+                    if (write_pass) out_keys[at + found] = tk;
+                    ++found;
+                }
+            });
+        }
+        if (!write_pass) counts[t] = found;
     }
 };
 
 // contacts of the initial-state sweep whose two slots are untouched by the
-// current hypothesis keep their initial status: carry them over
+// current hypothesis keep their initial status: carry them over (same two-pass
+// scheme; its counts follow the re-test's in the same array)
 struct ContactCarryClean {
     int64_t n;
     GridView g;
     const uint64_t* h0keys;
     const int32_t* cseg;
+    uint32_t* counts;
+    const uint32_t* offsets;
     uint64_t* out_keys;
-    uint32_t* counter;
-    uint32_t cap;
+    int32_t write_pass;
     PSIM_HD void operator()(int64_t h) const
     {
+        if (write_pass) {
+            if (counts[h]) out_keys[offsets[h]] = h0keys[h];
+            return;
+        }
         uint32_t si, sj;
         decode_pair_key(g, h0keys[h], &si, &sj);
-        if (cseg[si] < 0 && cseg[sj] < 0) {
-            uint32_t at = atomic_inc_u32(counter, 1);
-            if (at < cap) out_keys[at] = h0keys[h];
-        }
+        counts[h] = (cseg[si] < 0 && cseg[sj] < 0) ? 1u : 0u;
     }
 };
 
@@ -750,7 +831,7 @@ struct CompareKeys {
     uint32_t* mismatch;
     PSIM_HD void operator()(int64_t i) const
     {
-        if (a[i] != b[i]) atomic_inc_u32(mismatch, 1);
+        if (a[i] != b[i]) aggregated_inc(mismatch);
     }
 };
 
@@ -768,8 +849,7 @@ struct ContactFinalize {
     int32_t* cseg;
     const uint32_t* hsi;
     const BodyState* out;
-    const uint32_t* cperm;
-    vec2* cpos;
+    CellBody* body;
     vec2* pos;
     vec2* vel;
     double* temp;
@@ -781,9 +861,10 @@ struct ContactFinalize {
         uint32_t h = (uint32_t)adj[e];
         int side = (hsi[h] == x) ? 0 : 1;
         BodyState s = out[2 * h + side];
-        uint32_t p = cperm[x];
+        uint32_t p = body[x].idx;
         cseg[x] = -1;
-        cpos[x] = s.pos;
+        body[x].x = s.pos.x;
+        body[x].y = s.pos.y;
         pos[p] = s.pos;
         vel[p] = s.vel;
         temp[p] = s.temp;
@@ -796,7 +877,7 @@ struct ContactLog {
     int64_t n;
     const uint32_t* hsi;
     const uint32_t* hsj;
-    const uint32_t* cperm;
+    const CellBody* body;
     const double* vals;
     int32_t* log_ij;          // may be null
     double* log_vals;         // may be null
@@ -812,8 +893,8 @@ struct ContactLog {
         sum_heat[h] = heat > 0 ? heat : 0.0;
         int64_t at = log_base + h;
         if (log_ij && at < log_cap) {
-            log_ij[2 * at] = (int32_t)cperm[hsi[h]];
-            log_ij[2 * at + 1] = (int32_t)cperm[hsj[h]];
+            log_ij[2 * at] = (int32_t)body[hsi[h]].idx;
+            log_ij[2 * at + 1] = (int32_t)body[hsj[h]].idx;
             log_vals[3 * at] = pe; log_vals[3 * at + 1] = ke; log_vals[3 * at + 2] = heat;
         }
     }
@@ -822,16 +903,17 @@ struct ContactLog {
 // --------------------------------------------------------------- stage 7/8: conduction + cooling
 struct GatherThermal {
     int64_t n;
-    const uint32_t* cperm;
+    const CellBody* body;
     const double* temp;
     const double* mass;
-    double* ctemp;
-    double* cmass;
+    vec2* ctm;                // slot -> {temperature, mass}
     PSIM_HD void operator()(int64_t k) const
     {
-        uint32_t p = cperm[k];
-        ctemp[k] = temp[p];
-        cmass[k] = mass[p];
+        uint32_t p = body[k].idx;
+        vec2 v;
+        v.x = temp[p];
+        v.y = mass[p];
+        ctm[k] = v;
     }
 };
 
@@ -842,10 +924,7 @@ struct GatherThermal {
 struct Conduction {
     int64_t n;
     GridView g;
-    const vec2* cpos;
-    const int32_t* crad;
-    const double* ctemp;
-    const double* cmass;
+    const vec2* ctm;
     double heat_coeff;
     double cool_factor;       // 1 - damping
     int32_t do_conduct, do_cool;
@@ -854,28 +933,25 @@ struct Conduction {
     PSIM_HD void operator()(int64_t kk) const
     {
         uint32_t k = (uint32_t)kk;
-        uint32_t p = g.cperm[k];
-        double T = ctemp[k];
+        const CellBody me = g.body[k];
+        uint32_t p = me.idx;
+        double T = ctm[k].x;
         double delta = 0.0;
         if (do_conduct) {
-            vec2 P = cpos[k];
-            int32_t rp = crad[k];
-            double m = cmass[k];
-            const Conduction* self = this;
-            double* dptr = &delta;
-            for_each_neighbour_slot(g, k, [=](uint32_t y) {
-                vec2 Q = self->cpos[y];
-                double dx = Q.x - P.x, dy = Q.y - P.y;
+            double m = ctm[k].y;
+            for_each_neighbour_slot(g, k, [&](uint32_t y) {
+                const CellBody o = g.body[y];
+                double dx = o.x - me.x, dy = o.y - me.y;
                 double d2 = dx * dx + dy * dy;
-                int64_t cd = (int64_t)rp + (int64_t)self->crad[y];
+                int64_t cd = (int64_t)me.r + (int64_t)o.r;
                 if (d2 < (double)(cd * cd)) {
-                    double Tq = self->ctemp[y];
-                    if (p < self->g.cperm[y]) {
+                    double Tq = ctm[y].x;
+                    if (p < o.idx) {
                         double diff = T - Tq;
-                        if (diff != 0) *dptr -= (self->heat_coeff * diff) / m;
+                        if (diff != 0) delta -= (heat_coeff * diff) / m;
                     } else {
                         double diff = Tq - T;
-                        if (diff != 0) *dptr += (self->heat_coeff * diff) / m;
+                        if (diff != 0) delta += (heat_coeff * diff) / m;
                     }
                 }
             });
@@ -926,7 +1002,7 @@ struct WallsFlag {
         if (do_flag) {
             uint8_t b = temp[i] >= explode_temp ? 1 : 0;
             boom[i] = b;
-            if (b) atomic_inc_u32(boom_count, 1);
+            if (b) aggregated_inc(boom_count);
         }
     }
 };
@@ -964,39 +1040,43 @@ struct ExplosionGather {
     double efficiency;
     double* ex_energy;
     double* ex_total_w;
-    uint32_t* ex_count;
-    uint64_t* entries;
-    uint32_t* entry_counter;
-    uint32_t cap;
+    uint32_t* ex_count;        // pass 0: written; pass 1: read
+    const uint32_t* offsets;   // pass 1: exclusive scan of ex_count
+    uint64_t* entries;         // pass 1
+    int32_t write_pass;
     PSIM_HD void operator()(int64_t r) const
     {
         uint32_t p = list[r];
         vec2 P = pos[p];
-        double energy = (mass[p] * temp[p]) * efficiency;
         int64_t cx = (int64_t)(P.x / cell_size), cy = (int64_t)(P.y / cell_size);
         double total = 0.0;
         uint32_t cnt = 0;
+        uint32_t at = write_pass ? offsets[r] : 0u;
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 int64_t x = cx + dx, y = cy + dy;
                 if (x < 0 || x >= g.gw || y < 0 || y >= g.gh) continue;
                 int64_t c = y * g.gw + x;
                 for (int32_t k = g.offsets[c]; k < g.offsets[c + 1]; ++k) {
-                    uint32_t q = g.cperm[k];
+                    uint32_t q = g.body[k].idx;
                     if (q == p || boom[q]) continue;
-                    vec2 Q = pos[q];
-                    double ddx = Q.x - P.x, ddy = Q.y - P.y;
-                    double d2 = ddx * ddx + ddy * ddy;
-                    if (d2 == 0) d2 = 1e-6;
-                    total += 1.0 / d2;
+                    if (write_pass) {
+                        entries[at + cnt] = ((uint64_t)q << 32) | (uint64_t)r;
+                    } else {
+                        vec2 Q = pos[q];
+                        double ddx = Q.x - P.x, ddy = Q.y - P.y;
+                        double d2 = ddx * ddx + ddy * ddy;
+                        if (d2 == 0) d2 = 1e-6;
+                        total += 1.0 / d2;
+                    }
                     ++cnt;
-                    uint32_t at = atomic_inc_u32(entry_counter, 1);
-                    if (at < cap) entries[at] = ((uint64_t)q << 32) | (uint64_t)r;
                 }
             }
-        ex_energy[r] = energy;
-        ex_total_w[r] = total;
-        ex_count[r] = cnt;
+        if (!write_pass) {
+            ex_energy[r] = (mass[p] * temp[p]) * efficiency;
+            ex_total_w[r] = total;
+            ex_count[r] = cnt;
+        }
     }
 };
 

@@ -67,6 +67,7 @@ public:
     int64_t tree_n = 0;            // particle count the tree / grid were built for
     uint32_t n_internal = 0;
     int sorted_key = 0, sorted_ckey = 0;
+    int slot_bits = 1;            // pair-key field width, from the largest cell population
 
     // state (index space; reference layout particle_system.py:370-376, radii narrowed)
     DevBuf<vec2> pos, vel, acc, acc2;
@@ -94,16 +95,15 @@ public:
     // grid
     DevBuf<uint32_t> ckey[2], cperm[2];
     DevBuf<int32_t> offsets;
-    DevBuf<vec2> cpos;
-    DevBuf<int32_t> crad;
-    DevBuf<double> ctemp, cmass;
+    DevBuf<CellBody> cbody;
+    DevBuf<vec2> ctm;
     DevBuf<int32_t> cseg;
     bool cseg_ready = false;
 
     // collisions
     size_t ccap = 0;
     DevBuf<uint64_t> h0[2], hc[2], hn[2], adj[2];
-    DevBuf<uint32_t> hsi, hsj, done;
+    DevBuf<uint32_t> hsi, hsj, done, pcount, poffs;
     DevBuf<int32_t> prevl;
     DevBuf<BodyState> outst;
     DevBuf<double> cvals, sum_pe, sum_ke, sum_heat;
@@ -113,7 +113,7 @@ public:
 
     // explosions
     DevBuf<uint8_t> boom;
-    DevBuf<uint32_t> tmp32, tmp32b, ex_list, ex_count;
+    DevBuf<uint32_t> tmp32, tmp32b, ex_list, ex_count, ex_offs;
     DevBuf<double> ex_energy, ex_total;
     DevBuf<uint64_t> ex_entries[2];
     size_t ecap = 0;
@@ -215,11 +215,11 @@ public:
     GridView grid_view() const
     {
         GridView g;
-        g.cperm = cperm[sorted_ckey].p;
-        g.ckey = ckey[sorted_ckey].p;
+        g.body = cbody.p;
         g.offsets = offsets.p;
         g.gw = cfg.grid_w;
         g.gh = cfg.grid_h;
+        g.slot_bits = slot_bits;
         return g;
     }
 
@@ -250,8 +250,8 @@ public:
         sorted_ckey = be::radix_sort_pairs<uint32_t>(st, k, v, (uint64_t)n, 0, bits, sort_tmp.p);
         offsets.ensure(cells + 1);
         be::launch(st, n + 1, SegmentOffsets{n, ckey[sorted_ckey].p, offsets.p, (uint32_t)cells});
-        cpos.ensure(c); crad.ensure(c);
-        be::launch(st, n, GatherCell{n, cperm[sorted_ckey].p, pos.p, radii.p, cpos.p, crad.p});
+        cbody.ensure(c);
+        be::launch(st, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pos.p, radii.p, cbody.p});
         tree_n = n;
     }
 
@@ -339,23 +339,36 @@ public:
     void collision_sweep()
     {
         GridView g = grid_view();
-        int key_bits = 40 + ceil_log2_u64((uint64_t)cfg.grid_w * cfg.grid_h);
-        if (key_bits > 64) key_bits = 64;
-        int adj_bits = 32 + ceil_log2_u64((uint64_t)n + 1);
-        // ---- sweep against the initial positions
+        const int slot_field_bits = ceil_log2_u64((uint64_t)n + 1);
+        // ---- sweep against the initial positions (count, scan, write)
         uint32_t n0 = 0, cand = 0;
-        for (;;) {
+        int key_bits = 64;
+        const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
+        {
+            size_t c = (size_t)n;
+            pcount.ensure(c); poffs.ensure(c); scan_tmp.ensure(be::scan_temp_words(c));
             be::dev_memset(st, counters.p, 0, 64);
             ContactDetect d;
-            d.n = n; d.g = g; d.cpos = cpos.p; d.crad = crad.p; d.out_keys = h0[0].p; d.counter = counters.p;
-            d.cap = (uint32_t)ccap; d.cand_counter = cfg.debug ? counters.p + 1 : nullptr;
+            d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
+            d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? counters.p + 1 : nullptr;
             be::launch(st, n, d);
-            uint32_t two[2];
-            be::copy_d2h(st, two, counters.p, 8);
+            be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)n, scan_tmp.p, counters.p);
+            be::launch(st, cells, MaxOccupancy{cells, offsets.p, counters.p + 2});
+            uint32_t three[3];
+            be::copy_d2h(st, three, counters.p, 12);
             be::sync(st);
-            n0 = two[0]; cand = two[1];
-            if (n0 <= ccap) break;
-            ensure_contact_capacity(n0);
+            n0 = three[0]; cand = three[1];
+            slot_bits = ceil_log2_u64((uint64_t)three[2] + 1);
+            if (slot_bits < 1) slot_bits = 1;
+            g.slot_bits = slot_bits;
+            key_bits = ceil_log2_u64((uint64_t)cells) + 4 + 2 * slot_bits;
+            if (key_bits > 64) throw std::runtime_error("psim: grid cell population too large for the pair-key layout");
+            if (n0 > 0) {
+                ensure_contact_capacity(n0);
+                d.g = g;
+                d.out_keys = h0[0].p; d.write_pass = 1; d.cand_counter = nullptr;
+                be::launch(st, n, d);
+            }
         }
         n_candidates += cand;
         if (n0 == 0) return;
@@ -373,39 +386,58 @@ public:
             // ---- execute the hypothesis in order
             be::launch(st, nH, ContactDecode{(int64_t)nH, g, H, hsi.p, hsj.p, adj[0].p, done.p});
             uint64_t* ka[2] = {adj[0].p, adj[1].p};
-            int sa = be::radix_sort_pairs<uint64_t>(st, ka, nullptr, 2ull * nH, 0, adj_bits, sort_tmp.p);
+            // entries are generated in ascending contact order, so a stable sort on the slot
+            // field alone leaves each slot's contacts in order
+            int sa = be::radix_sort_pairs<uint64_t>(st, ka, nullptr, 2ull * nH, 32, 32 + slot_field_bits, sort_tmp.p);
             adjs = adj[sa].p;
             be::launch(st, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p});
-            uint32_t remaining = nH;
-            for (uint32_t round = 1; remaining > 0; ++round) {
-                be::dev_memset(st, counters.p, 0, 4);
-                ContactSimulate s;
-                s.n = nH; s.hsi = hsi.p; s.hsj = hsj.p; s.prev = prevl.p; s.done = done.p; s.round = round;
-                s.out = outst.p; s.vals = cvals.p; s.executed = counters.p; s.cperm = g.cperm; s.cpos = cpos.p;
-                s.crad = crad.p; s.vel = vel.p; s.temp = temp.p; s.mass = mass.p; s.G = cfg.gravity_constant;
-                s.soft = cfg.softening; s.restitution = cfg.restitution; s.pos_correct = cfg.pos_correct;
-                be::launch(st, nH, s);
+            // rounds are launched four at a time between reads of the running count
+            // (a round with nothing ready is a no-op)
+            uint32_t executed = 0, round = 0;
+            be::dev_memset(st, counters.p, 0, 4);
+            while (executed < nH) {
+                for (int b = 0; b < 4; ++b) {
+                    ++round;
+                    ContactSimulate s;
+                    s.n = nH; s.hsi = hsi.p; s.hsj = hsj.p; s.prev = prevl.p; s.done = done.p; s.round = round;
+                    s.out = outst.p; s.vals = cvals.p; s.executed = counters.p; s.body = cbody.p;
+                    s.vel = vel.p; s.temp = temp.p; s.mass = mass.p; s.G = cfg.gravity_constant;
+                    s.soft = cfg.softening; s.restitution = cfg.restitution; s.pos_correct = cfg.pos_correct;
+                    be::launch(st, nH, s);
+                }
                 uint32_t ex = read_u32(counters.p);
-                ++solver_rounds;
-                if (ex == 0 || ex > remaining) throw std::runtime_error("psim: internal: contact schedule stalled");
-                remaining -= ex;
+                solver_rounds += 4;
+                if (ex <= executed || ex > nH) throw std::runtime_error("psim: internal: contact schedule stalled");
+                executed = ex;
             }
-            // ---- re-test what the hypothesis could have changed
+            // ---- re-test what the hypothesis could have changed (count, scan, write)
             uint32_t nNew = 0;
-            for (;;) {
-                be::dev_memset(st, counters.p, 0, 4);
+            {
+                int64_t nt = 20ll * nH, ntot = nt + n0;
+                pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot);
+                scan_tmp.ensure(be::scan_temp_words((uint64_t)ntot));
                 ContactRetest r;
                 r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outst.p;
-                r.cpos = cpos.p; r.crad = crad.p; r.out_keys = hn[0].p; r.counter = counters.p; r.cap = (uint32_t)ccap;
-                be::launch(st, 2ll * nH, r);
-                be::launch(st, n0, ContactCarryClean{(int64_t)n0, g, H0, cseg.p, hn[0].p, counters.p, (uint32_t)ccap});
+                r.counts = pcount.p; r.offsets = poffs.p; r.out_keys = nullptr;
+                r.write_pass = 0;
+                ContactCarryClean cc{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
+                be::launch(st, nt, r);
+                be::launch(st, n0, cc);
+                be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)ntot, scan_tmp.p, counters.p);
                 nNew = read_u32(counters.p);
-                if (nNew <= ccap) break;
-                // growing reallocates every contact buffer: restart the whole sweep
-                be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
-                ensure_contact_capacity(nNew);
-                collision_sweep();
-                return;
+                if (nNew > ccap) {
+                    // growing reallocates every contact buffer: restart the whole sweep
+                    be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+                    ensure_contact_capacity(nNew);
+                    collision_sweep();
+                    return;
+                }
+                if (nNew > 0) {
+                    r.out_keys = hn[0].p; r.write_pass = 1;
+                    cc.out_keys = hn[0].p; cc.write_pass = 1;
+                    be::launch(st, nt, r);
+                    be::launch(st, n0, cc);
+                }
             }
             uint64_t* kn[2] = {hn[0].p, hn[1].p};
             hn_which = be::radix_sort_pairs<uint64_t>(st, kn, nullptr, nNew, 0, key_bits, sort_tmp.p);
@@ -437,7 +469,7 @@ public:
             }
         }
         ContactLog cl;
-        cl.n = nH; cl.hsi = hsi.p; cl.hsj = hsj.p; cl.cperm = g.cperm; cl.vals = cvals.p;
+        cl.n = nH; cl.hsi = hsi.p; cl.hsj = hsj.p; cl.body = cbody.p; cl.vals = cvals.p;
         cl.log_ij = cfg.debug ? log_ij.p : nullptr; cl.log_vals = cfg.debug ? log_vals.p : nullptr;
         cl.log_base = log_n; cl.log_cap = (int64_t)log_cap;
         cl.sum_pe = sum_pe.p; cl.sum_ke = sum_ke.p; cl.sum_heat = sum_heat.p;
@@ -446,8 +478,8 @@ public:
         be::reduce_sum_f64(st, sum_ke.p, nH, red_tmp.p, red_out.p + 1);
         be::reduce_sum_f64(st, sum_heat.p, nH, red_tmp.p, red_out.p + 2);
         ContactFinalize f;
-        f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outst.p; f.cperm = g.cperm;
-        f.cpos = cpos.p; f.pos = pos.p; f.vel = vel.p; f.temp = temp.p;
+        f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outst.p; f.body = cbody.p;
+        f.pos = pos.p; f.vel = vel.p; f.temp = temp.p;
         be::launch(st, 2ll * nH, f);
         be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
         double t[3];
@@ -470,12 +502,12 @@ public:
             return;
         }
         size_t c = (size_t)n;
-        ctemp.ensure(c); cmass.ensure(c);
+        ctm.ensure(c);
         GridView g = grid_view();
-        be::launch(st, n, GatherThermal{n, g.cperm, temp.p, mass.p, ctemp.p, cmass.p});
+        be::launch(st, n, GatherThermal{n, cbody.p, temp.p, mass.p, ctm.p});
         if (cfg.debug) delta_dbg.ensure(c);
         Conduction k;
-        k.n = n; k.g = g; k.cpos = cpos.p; k.crad = crad.p; k.ctemp = ctemp.p; k.cmass = cmass.p;
+        k.n = n; k.g = g; k.ctm = ctm.p;
         k.heat_coeff = cfg.heat_coeff; k.cool_factor = factor; k.do_conduct = 1; k.do_cool = cool ? 1 : 0;
         k.temp = temp.p; k.delta_out = cfg.debug ? delta_dbg.p : nullptr;
         be::launch(st, n, k);
@@ -506,26 +538,29 @@ public:
         be::launch(st, n, FlagToU32{n, boom.p, tmp32.p, 0});
         be::exclusive_scan_u32(st, tmp32.p, tmp32b.p, (uint64_t)n, scan_tmp.p, nullptr);
         be::launch(st, n, ExploderList{n, boom.p, tmp32b.p, ex_list.p});
-        if (ecap == 0) { ecap = (size_t)count * 64 + 1024; ex_entries[0].ensure(ecap); ex_entries[1].ensure(ecap); }
         uint32_t ne = 0;
-        for (;;) {
-            be::dev_memset(st, counters.p, 0, 4);
+        {
             ExplosionGather k;
             k.n_ex = count; k.list = ex_list.p; k.g = g; k.cell_size = (double)cfg.cell_size; k.pos = pos.p;
             k.mass = mass.p; k.temp = temp.p; k.boom = boom.p; k.efficiency = cfg.explosion_eff;
             k.ex_energy = ex_energy.p; k.ex_total_w = ex_total.p; k.ex_count = ex_count.p;
-            k.entries = ex_entries[0].p; k.entry_counter = counters.p; k.cap = (uint32_t)ecap;
+            ex_offs.ensure(count);
+            k.offsets = ex_offs.p; k.entries = nullptr; k.write_pass = 0;
             be::launch(st, count, k);
+            be::exclusive_scan_u32(st, ex_count.p, ex_offs.p, (uint64_t)count, scan_tmp.p, counters.p);
             ne = read_u32(counters.p);
-            if (ne <= ecap) break;
-            ecap = (size_t)ne + ne / 4 + 1024;
-            ex_entries[0].ensure(ecap); ex_entries[1].ensure(ecap);
+            if (ne > 0) {
+                if (ne > ecap) { ecap = (size_t)ne + ne / 4 + 1024; ex_entries[0].ensure(ecap); ex_entries[1].ensure(ecap); }
+                k.entries = ex_entries[0].p; k.write_pass = 1;
+                be::launch(st, count, k);
+            }
         }
         if (ne > 0) {
             sort_tmp.ensure(be::sort_temp_words(ne));
             uint64_t* ke[2] = {ex_entries[0].p, ex_entries[1].p};
+            // written in ascending exploder rank: a stable sort on the neighbour field suffices
             int bits = 32 + ceil_log2_u64((uint64_t)n + 1);
-            int se = be::radix_sort_pairs<uint64_t>(st, ke, nullptr, ne, 0, bits, sort_tmp.p);
+            int se = be::radix_sort_pairs<uint64_t>(st, ke, nullptr, ne, 32, bits, sort_tmp.p);
             be::launch(st, ne, ExplosionApply{(int64_t)ne, ex_entries[se].p, ex_list.p, pos.p, mass.p, ex_energy.p,
                                               ex_total.p, vel.p});
         }

@@ -28,15 +28,22 @@ struct alignas(32) NodeRec {
     uint32_t depth;
 };
 
+// One particle in cell-sorted ("slot") order: everything a neighbour test needs
+// in a single 32-byte record (position, integer radius, particle index, cell).
+struct alignas(32) CellBody {
+    double x, y;
+    int32_t r;
+    uint32_t idx;
+    uint32_t cell;
+    uint32_t pad;
+};
+
 constexpr uint32_t kLeaf = 255;
 constexpr int kKeyLevels = 32;          // Morton key: 32 levels x 2 bits
 constexpr int kMaxInternalDepth = 31;   // children of depth-31 nodes are bucket leaves
 
 // ordering key of a candidate pair inside one collision sweep
-// (cell:24 | phase:4 | a:18 | b:18), see pair_key()
-constexpr int kSlotBits = 18;
-constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1;
-constexpr uint32_t kMaxCellOccupancy = kSlotMask;   // per-cell particle limit
+// (cell | phase:4 | a | b, field widths chosen per step), see make_pair_key()
 constexpr uint32_t kMaxCells = 1u << 24;
 
 enum StageBits : int32_t {

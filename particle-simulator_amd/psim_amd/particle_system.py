@@ -243,8 +243,9 @@ class ParticleSystem:
         return dict(zip(keys, out))
 
     def walk_counts(self):
-        out = (ctypes.c_int64 * 2)()
+        out = (ctypes.c_int64 * 4)()
         _capi.check(self._lib, self._lib.psim_walk_counts(self._ctx, out))
+        self.last_walk_trips = (int(out[2]), int(out[3]))
         return int(out[0]), int(out[1])
 
     def stage_times_ms(self):
