@@ -91,6 +91,26 @@ int psim_prime_gravity(psim_context* ctx);
 /* replaces: ParticleSystem.update() called k_steps times (particle_system.py:518-563) */
 int psim_step(psim_context* ctx, int64_t k_steps);
 
+/* One simulation sharded over several GPUs (no counterpart in the reference, which
+ * is single-process): psim_step cut at its two exchange points.  Every rank holds
+ * the full state and calls all five in order; between them the caller all-gathers
+ * the device buffers (RCCL):
+ *   psim_stage_build         drift, grid, tree (identical on every rank)
+ *   psim_stage_gravity       walk for the sorted particles [s_lo, s_hi) -> acc_sorted[s]
+ *                            (device pointer, (n,2) float64, indexed by sorted position)
+ *   -- all-gather acc_sorted --
+ *   psim_stage_kick_collide  kick from the gathered accelerations; contact solver
+ *   psim_stage_conduction    conduction + cooling for grid slots [k_lo, k_hi) ->
+ *                            temp_slots[k] (device pointer, (n) float64, slot order)
+ *   -- all-gather temp_slots --
+ *   psim_stage_finish        temperatures back to particle order; walls; explosions
+ * Results are bit-identical to psim_step for any split of the ranges. */
+int psim_stage_build(psim_context* ctx);
+int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* acc_sorted);
+int psim_stage_kick_collide(psim_context* ctx, const double* acc_sorted);
+int psim_stage_conduction(psim_context* ctx, int64_t k_lo, int64_t k_hi, double* temp_slots);
+int psim_stage_finish(psim_context* ctx, const double* temp_slots);
+
 /* replaces: get_total_kinetic_energy / get_total_potential_energy /
  * get_total_thermal_energy (particle_system.py:765-804); out[0..2] = KE, PE, TE,
  * out[3..4] = total momentum (sum m v), which the reference does not report. */

@@ -397,13 +397,15 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
-    int64_t n, const NodeRec* __restrict__ rec, uint32_t total_elems, const vec2* __restrict__ spos,
-    const double* __restrict__ smass, const uint32_t* __restrict__ perm, const double* __restrict__ inv_mass,
-    vec2* __restrict__ acc_out, double w2_root, double theta2, double g_const, double softening,
-    unsigned long long* __restrict__ counters)
+    int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
+    const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
+    const double* __restrict__ inv_mass, vec2* __restrict__ acc_out, double w2_root, double theta2, double g_const,
+    double softening, unsigned long long* __restrict__ counters)
 {
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = s < n;
+    // targets are the sorted particles [s_begin, s_end); results go to acc_out[particle
+    // index] or, for a sharded walk, to acc_out[sorted position]
+    const int64_t s = s_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = s < s_end;
     double px = 0.0, py = 0.0;
     if (live) { vec2 p = spos[s]; px = p.x; py = p.y; }
     uint32_t until = live ? 0u : 0xffffffffu;
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
         vec2 a;
         a.x = (gm * ax) * im;
         a.y = (gm * ay) * im;
-        acc_out[p] = a;
+        acc_out[sorted_out ? (uint32_t)s : p] = a;
     }
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)visits);

@@ -19,18 +19,17 @@ static_assert(sizeof(psim_explosion_event) == sizeof(psim::ExplosionEvent), "eve
 
 namespace psim {
 
-void Sim::gravity(vec2* out)
+void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
 {
-    if (n == 0) return;
+    if (hi <= lo) return;
     uint32_t total = (uint32_t)(n + n_internal);
     double theta2 = cfg.theta * cfg.theta;          // particle_system.py:88 theta * theta * dist_sq
 #if !defined(PSIM_HOSTLOOP)
     if (cfg.walk_mode == 0) {
-        int64_t blocks = (n + 255) / 256;
-        auto kern = be::gravity_walk_wave_kernel<false>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0,
-                           st, n, (const NodeRec*)rec.p, total, (const vec2*)spos.p, (const double*)smass.p,
-                           (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p, out,
+        int64_t blocks = (hi - lo + 255) / 256;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(be::gravity_walk_wave_kernel<false>), dim3((unsigned)blocks), dim3(256), 0,
+                           st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
+                           (const double*)smass.p, (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p, out,
                            cfg.bounds_w * cfg.bounds_w, theta2, cfg.gravity_constant, cfg.softening,
                            (unsigned long long*)nullptr);
         PSIM_HIP(hipGetLastError());
@@ -38,11 +37,13 @@ void Sim::gravity(vec2* out)
     }
 #endif
     GravityWalkSimple k;
-    k.n = n; k.rec = rec.p; k.total_elems = total; k.spos = spos.p; k.smass = smass.p; k.perm = perm[sorted_key].p;
-    k.inv_mass = inv_mass.p; k.acc_out = out; k.w2tab = w2tab.p; k.theta2 = theta2; k.g_const = cfg.gravity_constant;
-    k.softening = cfg.softening; k.counters = nullptr;
-    be::launch(st, n, k);
+    k.n = hi - lo; k.s0 = lo; k.sorted_out = sorted_out ? 1 : 0; k.rec = rec.p; k.total_elems = total; k.spos = spos.p;
+    k.smass = smass.p; k.perm = perm[sorted_key].p; k.inv_mass = inv_mass.p; k.acc_out = out; k.w2tab = w2tab.p;
+    k.theta2 = theta2; k.g_const = cfg.gravity_constant; k.softening = cfg.softening; k.counters = nullptr;
+    be::launch(st, hi - lo, k);
 }
+
+void Sim::gravity(vec2* out) { gravity_range(0, n, out, false); }
 
 }  // namespace psim
 
@@ -167,6 +168,51 @@ int psim_step(psim_context* ctx, int64_t k_steps)
     })
 }
 
+int psim_stage_build(psim_context* ctx)
+{
+    PSIM_TRY(ctx, {
+        use_device(ctx->device);
+        ctx->sim->stage_build();
+        psim::be::sync(ctx->sim->st);
+    })
+}
+
+int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* acc_sorted)
+{
+    PSIM_TRY(ctx && acc_sorted, {
+        use_device(ctx->device);
+        ctx->sim->stage_gravity(s_lo, s_hi, reinterpret_cast<psim::vec2*>(acc_sorted));
+        psim::be::sync(ctx->sim->st);
+    })
+}
+
+int psim_stage_kick_collide(psim_context* ctx, const double* acc_sorted)
+{
+    PSIM_TRY(ctx && acc_sorted, {
+        use_device(ctx->device);
+        ctx->sim->stage_kick_collide(reinterpret_cast<const psim::vec2*>(acc_sorted));
+        psim::be::sync(ctx->sim->st);
+    })
+}
+
+int psim_stage_conduction(psim_context* ctx, int64_t k_lo, int64_t k_hi, double* temp_slots)
+{
+    PSIM_TRY(ctx && temp_slots, {
+        use_device(ctx->device);
+        ctx->sim->stage_conduction(k_lo, k_hi, temp_slots);
+        psim::be::sync(ctx->sim->st);
+    })
+}
+
+int psim_stage_finish(psim_context* ctx, const double* temp_slots)
+{
+    PSIM_TRY(ctx && temp_slots, {
+        use_device(ctx->device);
+        ctx->sim->stage_finish(temp_slots);
+        psim::be::sync(ctx->sim->st);
+    })
+}
+
 int psim_energies(psim_context* ctx, double out[5])
 {
     PSIM_TRY(ctx && out, {
@@ -225,7 +271,7 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     psim::be::dev_memset(s->st, cnt.p, 0, 256);
     int64_t blocks = (s->n + 255) / 256;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(psim::be::gravity_walk_wave_kernel<true>), dim3((unsigned)blocks), dim3(256), 0,
-                       s->st, s->n, (const psim::NodeRec*)s->rec.p, total, (const psim::vec2*)s->spos.p,
+                       s->st, (int64_t)0, s->n, 0, (const psim::NodeRec*)s->rec.p, total, (const psim::vec2*)s->spos.p,
                        (const double*)s->smass.p, (const uint32_t*)s->perm[s->sorted_key].p,
                        (const double*)s->inv_mass.p, scratch.p, s->cfg.bounds_w * s->cfg.bounds_w, theta2,
                        s->cfg.gravity_constant, s->cfg.softening, cnt.p);
@@ -249,7 +295,7 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     cnt.ensure(2);
     psim::be::dev_memset(s->st, cnt.p, 0, 8);
     psim::GravityWalkSimple k;
-    k.n = s->n; k.rec = s->rec.p; k.total_elems = total; k.spos = s->spos.p; k.smass = s->smass.p;
+    k.n = s->n; k.s0 = 0; k.sorted_out = 0; k.rec = s->rec.p; k.total_elems = total; k.spos = s->spos.p; k.smass = s->smass.p;
     k.perm = s->perm[s->sorted_key].p; k.inv_mass = s->inv_mass.p; k.acc_out = scratch.p; k.w2tab = s->w2tab.p;
     k.theta2 = theta2; k.g_const = s->cfg.gravity_constant; k.softening = s->cfg.softening; k.counters = cnt.p;
     psim::be::launch(s->st, s->n, k);

@@ -367,7 +367,9 @@ PSIM_HD PSIM_FORCEINLINE double inv_cube_soft(double x)
 }
 
 struct GravityWalkSimple {
-    int64_t n;
+    int64_t n;                  // number of targets (sorted particles s0 .. s0 + n - 1)
+    int64_t s0;
+    int32_t sorted_out;         // write acc_out[sorted position] instead of acc_out[particle index]
     const NodeRec* rec;
     uint32_t total_elems;
     const vec2* spos;
@@ -378,8 +380,9 @@ struct GravityWalkSimple {
     const double* w2tab;        // [32] squared node width per depth
     double theta2, g_const, softening;
     uint32_t* counters;         // optional [2]: visits, interactions
-    PSIM_HD void operator()(int64_t s) const
+    PSIM_HD void operator()(int64_t i) const
     {
+        int64_t s = s0 + i;
         double px = spos[s].x, py = spos[s].y;
         double ax = 0.0, ay = 0.0;
         uint32_t j = 0, visits = 0, inter = 0;
@@ -405,7 +408,7 @@ struct GravityWalkSimple {
         vec2 a;
         a.x = (gm * ax) * im;      // particle_system.py:25  a = F * (1/m)
         a.y = (gm * ay) * im;
-        acc_out[p] = a;
+        acc_out[sorted_out ? (uint32_t)s : p] = a;
         if (counters) {
             atomic_inc_u32(&counters[0], visits);
             atomic_inc_u32(&counters[1], inter);
@@ -928,11 +931,13 @@ struct Conduction {
     double heat_coeff;
     double cool_factor;       // 1 - damping
     int32_t do_conduct, do_cool;
-    double* temp;             // index space, written
+    double* temp;             // index space, written (when temp_slots is null)
+    double* temp_slots;       // slot space, written instead (sharded sweep)
     double* delta_out;        // optional debug, index space
+    int64_t k0;               // first slot of this launch
     PSIM_HD void operator()(int64_t kk) const
     {
-        uint32_t k = (uint32_t)kk;
+        uint32_t k = (uint32_t)(k0 + kk);
         const CellBody me = g.body[k];
         uint32_t p = me.idx;
         double T = ctm[k].x;
@@ -958,9 +963,25 @@ struct Conduction {
         }
         double T1 = T + delta;
         if (do_cool) T1 = T1 * cool_factor;
-        temp[p] = T1;
+        if (temp_slots) temp_slots[k] = T1; else temp[p] = T1;
         if (delta_out) delta_out[p] = delta;
     }
+};
+
+// results of a sharded stage, gathered in sorted / slot order, back to index order
+struct ScatterSorted {
+    int64_t n;
+    const uint32_t* perm;
+    const vec2* in_sorted;
+    vec2* out;
+    PSIM_HD void operator()(int64_t s) const { out[perm[s]] = in_sorted[s]; }
+};
+struct ScatterSlots {
+    int64_t n;
+    const CellBody* body;
+    const double* in_slots;
+    double* out;
+    PSIM_HD void operator()(int64_t k) const { out[body[k].idx] = in_slots[k]; }
 };
 
 struct Cooling {

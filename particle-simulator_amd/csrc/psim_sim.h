@@ -309,6 +309,7 @@ public:
     }
 
     void gravity(vec2* out);   // defined after the back end's walk kernel (psim_capi.cpp)
+    void gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out);
 
     // particle_system.py:439-474
     void ensure_contact_capacity(size_t want)
@@ -490,15 +491,16 @@ public:
         if (cfg.debug) log_n += nH;
     }
 
-    // particle_system.py:476-498 + :555-557
-    void conduction_and_cooling()
+    // particle_system.py:476-498 + :555-557.  Slots [lo, hi) only; with temp_slots the
+    // new temperatures are written in slot order (sharded sweep) instead of to temp[].
+    void conduction_and_cooling(int64_t lo, int64_t hi, double* temp_slots)
     {
         bool cond = (cfg.stage_mask & kStageConduction) != 0;
         bool cool = (cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0;
         if (n == 0 || (!cond && !cool)) return;
         double factor = 1.0 - cfg.damping;
         if (!cond) {
-            be::launch(st, n, Cooling{n, temp.p, factor});
+            if (!temp_slots) be::launch(st, n, Cooling{n, temp.p, factor});
             return;
         }
         size_t c = (size_t)n;
@@ -506,12 +508,14 @@ public:
         GridView g = grid_view();
         be::launch(st, n, GatherThermal{n, cbody.p, temp.p, mass.p, ctm.p});
         if (cfg.debug) delta_dbg.ensure(c);
+        if (hi <= lo) return;
         Conduction k;
-        k.n = n; k.g = g; k.ctm = ctm.p;
+        k.n = hi - lo; k.g = g; k.ctm = ctm.p;
         k.heat_coeff = cfg.heat_coeff; k.cool_factor = factor; k.do_conduct = 1; k.do_cool = cool ? 1 : 0;
-        k.temp = temp.p; k.delta_out = cfg.debug ? delta_dbg.p : nullptr;
-        be::launch(st, n, k);
+        k.temp = temp.p; k.temp_slots = temp_slots; k.delta_out = cfg.debug ? delta_dbg.p : nullptr; k.k0 = lo;
+        be::launch(st, hi - lo, k);
     }
+    void conduction_and_cooling() { conduction_and_cooling(0, n, nullptr); }
 
     // particle_system.py:500-516 and the explosion test of :658
     uint32_t walls_and_flags()
@@ -625,6 +629,55 @@ public:
         timer.mark(st, 6);
         conduction_and_cooling();
         timer.mark(st, 7);
+        uint32_t nb = walls_and_flags();
+        if (nb > 0) explosions(nb);
+        timer.mark(st, 8);
+    }
+
+    // ---- the same step cut at its exchange points, for one simulation sharded over
+    // several GPUs: every rank holds the full state and builds the same grid and tree;
+    // the walk and the conduction sweep run on a rank's share of sorted particles /
+    // grid slots and their outputs are all-gathered by the caller between stages.
+    void stage_build()
+    {
+        n_exploded = 0;
+        last_exploded.clear();
+        timer.mark(st, 0);
+        keys_and_drift(true);
+        timer.mark(st, 1);
+        build_grid();
+        timer.mark(st, 2);
+        build_tree();
+        timer.mark(st, 3);
+    }
+    void stage_gravity(int64_t lo, int64_t hi, vec2* acc_sorted)
+    {
+        if (lo < 0 || hi > n || lo > hi) throw std::invalid_argument("psim: bad sorted range");
+        gravity_range(lo, hi, acc_sorted, true);
+        timer.mark(st, 4);
+    }
+    void stage_kick_collide(const vec2* acc_sorted)
+    {
+        be::launch(st, n, ScatterSorted{n, perm[sorted_key].p, acc_sorted, acc2.p});
+        be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
+        acc.swap(acc2);
+        timer.mark(st, 5);
+        if (cfg.stage_mask & kStageCollisions) collisions();
+        else { coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0; n_candidates = n_contacts = 0; log_n = 0; }
+        timer.mark(st, 6);
+    }
+    void stage_conduction(int64_t lo, int64_t hi, double* temp_slots)
+    {
+        if (lo < 0 || hi > n || lo > hi) throw std::invalid_argument("psim: bad slot range");
+        conduction_and_cooling(lo, hi, temp_slots);
+        timer.mark(st, 7);
+    }
+    void stage_finish(const double* temp_slots)
+    {
+        bool cond = (cfg.stage_mask & kStageConduction) != 0;
+        bool cool = (cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0;
+        if (n > 0 && cond) be::launch(st, n, ScatterSlots{n, cbody.p, temp_slots, temp.p});
+        else if (n > 0 && cool) be::launch(st, n, Cooling{n, temp.p, 1.0 - cfg.damping});
         uint32_t nb = walls_and_flags();
         if (nb > 0) explosions(nb);
         timer.mark(st, 8);

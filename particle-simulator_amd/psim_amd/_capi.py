@@ -24,6 +24,8 @@ EXPORTS = [
     "psim_collision_stats", "psim_counts", "psim_explosion_events", "psim_walk_counts",
     "psim_debug_size", "psim_debug_fetch", "psim_selftest", "psim_stage_times",
     "psim_last_error", "psim_version",
+    "psim_stage_build", "psim_stage_gravity", "psim_stage_kick_collide", "psim_stage_conduction",
+    "psim_stage_finish",
 ]
 
 
@@ -90,6 +92,11 @@ def load(path=None):
     L.psim_debug_fetch.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t]
     L.psim_selftest.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_uint64]
     L.psim_stage_times.argtypes = [vp, c_dp]
+    L.psim_stage_build.argtypes = [vp]
+    L.psim_stage_gravity.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.psim_stage_kick_collide.argtypes = [vp, vp]
+    L.psim_stage_conduction.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp]
+    L.psim_stage_finish.argtypes = [vp, vp]
     L.psim_last_error.restype = ctypes.c_char_p
     L.psim_version.restype = ctypes.c_char_p
     for name in EXPORTS:

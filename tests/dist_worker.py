@@ -1,0 +1,58 @@
+"""Worker of tests/test_distributed_gloo.py (and of the single-GPU RCCL test):
+runs one golden case sharded over WORLD_SIZE ranks and checks that the state
+is bit-identical to an unsharded run of the same library."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT, os.path.join(ROOT, "particle-simulator_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from conftest import load_golden
+from psim_amd.particle_system import ParticleSystem
+from psim_amd.distributed import ShardedParticleSystem, shard_range
+
+
+def main():
+    backend, library, name, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    library = None if library == "hip" else library
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    g = load_golden(name)
+    kw = dict(library=library, walk_mode=0 if library is None else 1, debug=True)
+    ref = ParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds, **kw)
+    sh = ShardedParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds, **kw)
+    v = g.init_velocities()
+    for s in (ref, sh):
+        if v is not None:
+            s.velocities[:] = v
+            s.push_state()
+        s._calculate_gravity()
+    for step in range(1, steps + 1):
+        ref.update()
+        sh.update()
+        assert ref.num_particles == sh.num_particles, (step, rank)
+        for f in ("positions", "velocities", "accelerations", "temperatures"):
+            a, b = getattr(ref, f), getattr(sh, f)
+            assert np.array_equal(a, b), (step, rank, f, float(np.abs(a - b).max()))
+        assert ref.counts() == sh.counts(), (step, rank)
+    # the shards tile the index space exactly
+    n = 1000003
+    cover = [shard_range(n, r, world) for r in range(world)]
+    assert cover[0][0] == 0 and cover[-1][1] == n
+    assert all(cover[i][1] == cover[i + 1][0] for i in range(world - 1))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok: %s, %d steps, n %d -> %d" % (rank, name, steps, g.n, sh.num_particles))
+
+
+if __name__ == "__main__":
+    main()

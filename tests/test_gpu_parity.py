@@ -86,3 +86,11 @@ def test_walk_variants_agree_and_counts():
     o._calculate_gravity()
     # the oracle counts empty leaves it never enters? no: it only enters children with mass > 0
     assert inter == o.last_interactions
+
+
+def test_sharded_step_over_rccl_single_rank():
+    """the staged (multi-GPU) entry points + RCCL all-gather on one rank: bit-identical
+    to psim_step on the golden cases (world_size > 1 is covered on CPU with gloo)"""
+    from test_distributed_gloo import run_ranks
+    run_ranks(1, "nccl", "hip", "dense256", 6)
+    run_ranks(1, "nccl", "hip", "hot300", 6)
