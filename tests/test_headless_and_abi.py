@@ -1,0 +1,121 @@
+"""Host logic on CPU: the C ABI library loads and exports every symbol that
+include/psim.h declares; the headless runner mirrors main.py's bookkeeping;
+config handling and error behaviour of the binding."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from psim_amd import _capi
+from psim_amd.particle_system import ParticleSystem, grid_geometry, make_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOSTLOOP_DIR = os.path.join(ROOT, "tests", "hostloop")
+HOSTLOOP = os.path.join(HOSTLOOP_DIR, "libpsim_hostloop.so")
+SIM = json.load(open(os.path.join(ROOT, "particle-simulator_amd", "config.json")))["simulation"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def build_hostloop():
+    subprocess.check_call(["make", "-s", "-C", HOSTLOOP_DIR])
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "psim.h")).read()
+    return sorted(set(re.findall(r"\b(psim_[a-z_]+)\s*\(", text)))
+
+
+def test_hip_library_exports_declared_abi():
+    """no compute calls: only dlopen + symbol lookup (works without a GPU)"""
+    assert os.path.exists(_capi.HIP_LIBRARY), "build libpsim_hip.so first (make -C particle-simulator_amd/csrc)"
+    L = ctypes.CDLL(_capi.HIP_LIBRARY)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(L, name), name
+    assert set(_capi.EXPORTS) == set(names)
+    assert b"HIP gfx950" in _capi.load().psim_version()
+
+
+def test_missing_library_raises():
+    with pytest.raises(ImportError):
+        _capi.load("/nonexistent/libpsim_hip.so")
+
+
+def test_grid_geometry_matches_reference_defaults():
+    # particle_system.py:381-390 at the default config: cell 80, 25 x 13 cells
+    assert grid_geometry(SIM, (2000, 1000)) == (80, 25, 13)
+    c = make_config(SIM, (2000, 1000))
+    assert (c.cell_size, c.grid_w, c.grid_h, c.solver_iterations) == (80, 25, 13, 1)
+    assert c.explode_temp == 1.0 and c.pos_correct == 1.05
+    sparse = {k: v for k, v in SIM.items() if k not in ("position_correction_factor", "explosion_efficiency",
+                                                        "thermal_damping_factor", "collision_solver_iterations",
+                                                        "grid_cell_size_multiplier")}
+    c = make_config(sparse, (2000, 1000))           # optional keys fall back to the reference's defaults
+    assert (c.pos_correct, c.explosion_eff, c.damping, c.solver_iterations, c.cell_size) == (1.0, 0.1, 0.0, 1, 8)
+
+
+def test_bad_arguments_are_value_errors():
+    L = _capi.load(HOSTLOOP)
+    cfg = make_config(SIM, (2000, 1000))
+    cfg.grid_w = 0
+    ctx = ctypes.c_void_p()
+    rc = L.psim_create(ctypes.byref(cfg), 0, ctypes.byref(ctx))
+    assert rc == -1 and b"grid" in L.psim_last_error()
+    with pytest.raises(ValueError):
+        _capi.check(L, rc)
+    assert L.psim_step(None, 1) == -1
+
+
+def test_empty_and_single_particle_systems():
+    for n in (0, 1, 2):
+        s = ParticleSystem(n, dict(SIM), np.random.default_rng(1), (200, 100), library=HOSTLOOP, walk_mode=1)
+        s._calculate_gravity()
+        s.update(3)
+        assert s.num_particles == n
+        assert s.positions.shape == (n, 2) and s.radii.dtype == np.int64
+        assert np.isfinite(s.get_energies()).all()
+        s.close()
+
+
+def test_config_is_reread_each_step():
+    """the reference holds the config dict by reference (particle_system.py:430,462,555)"""
+    cfg = dict(SIM)
+    a = ParticleSystem(300, cfg, np.random.default_rng(3), (400, 300), library=HOSTLOOP, walk_mode=1)
+    b = ParticleSystem(300, dict(SIM, gravity_constant=0.05), np.random.default_rng(3), (400, 300),
+                       library=HOSTLOOP, walk_mode=1)
+    a._calculate_gravity(); b._calculate_gravity()
+    assert not np.array_equal(a.accelerations, b.accelerations)
+    cfg['gravity_constant'] = 0.05          # mutate the dict the system holds
+    a._calculate_gravity()
+    np.testing.assert_array_equal(a.accelerations, b.accelerations)
+
+
+def test_headless_runner_logs_like_main(tmp_path, monkeypatch):
+    from psim_amd import headless
+    import psim_amd.particle_system as ps_mod
+    monkeypatch.chdir(tmp_path)
+    config = json.load(open(os.path.join(ROOT, "particle-simulator_amd", "config.json")))
+    config["simulation"]["particle_count"] = 400
+    headless.setup_logging(config)
+    orig = ps_mod.ParticleSystem.__init__
+
+    def patched(self, *a, **k):
+        k.setdefault("library", HOSTLOOP)
+        k.setdefault("walk_mode", 1)
+        orig(self, *a, **k)
+
+    monkeypatch.setattr(ps_mod.ParticleSystem, "__init__", patched)
+    system = headless.run(config, ticks=101, bounds=(800, 400))
+    assert system.num_particles == 400
+    log = open(tmp_path / "runs" / "sim_run_001" / "simulation.log").read()
+    lines = [l for l in log.splitlines() if "Tick=" in l]
+    assert len(lines) == 2 and "Tick=0," in lines[0] and "Tick=100," in lines[1]
+    for key in ("Kinetic=", "Thermal=", "Potential=", "TotalSystemEnergy=", "Delta_E=", "AccumulatedKE_Loss=",
+                "AccumulatedPE_Gain=", "AccumulatedHeat="):
+        assert key in lines[1]
+    assert "particle-updates/s" in log and "momentum=" in log
