@@ -41,6 +41,14 @@ inline void copy_d2d(Stream st, void* d, const void* s, size_t bytes)
     if (bytes) PSIM_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, st));
 }
 inline void sync(Stream st) { PSIM_HIP(hipStreamSynchronize(st)); }
+// page-locked host memory: small device-to-host readbacks land here without a staging copy
+inline void* host_alloc_pinned(size_t bytes)
+{
+    void* p = nullptr;
+    PSIM_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    return p;
+}
+inline void host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 
 // ------------------------------------------------------------------ launch
 template <class F>

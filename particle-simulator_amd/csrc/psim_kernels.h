@@ -134,11 +134,16 @@ struct MaxOccupancy {
     uint32_t* out;
     PSIM_HD void operator()(int64_t c) const
     {
-        uint32_t occ = (uint32_t)(offsets[c + 1] - offsets[c]);
+        // launched over `cells` rounded up to a multiple of 64, so whole waves are active
+        uint32_t occ = c < cells ? (uint32_t)(offsets[c + 1] - offsets[c]) : 0u;
 #if defined(PSIM_HOSTLOOP)
         if (occ > *out) *out = occ;
 #else
-        if (occ > *((volatile uint32_t*)out)) atomicMax(out, occ);
+        for (int o = 32; o > 0; o >>= 1) {      // wave maximum
+            uint32_t t = (uint32_t)__shfl_xor((int)occ, o, 64);
+            occ = t > occ ? t : occ;
+        }
+        if ((threadIdx.x & 63u) == 0u) atomicMax(out, occ);
 #endif
     }
 };
@@ -151,12 +156,15 @@ struct GatherCell {
     const vec2* pos;
     const int32_t* radii;
     CellBody* body;
+    int32_t gw;
     PSIM_HD void operator()(int64_t k) const
     {
         uint32_t p = cperm[k];
         vec2 P = pos[p];
         CellBody b;
-        b.x = P.x; b.y = P.y; b.r = radii[p]; b.idx = p; b.cell = ckey[k]; b.pad = 0;
+        uint32_t c = ckey[k];
+        b.x = P.x; b.y = P.y; b.r = radii[p]; b.idx = p; b.cell = c;
+        b.cxy = (c % (uint32_t)gw) | ((c / (uint32_t)gw) << 16);
         body[k] = b;
     }
 };
@@ -463,8 +471,9 @@ PSIM_HD PSIM_FORCEINLINE uint64_t pair_key(const GridView& g, uint32_t sx, uint3
     uint32_t a = lo - (uint32_t)g.offsets[cl], b = hi - (uint32_t)g.offsets[ch];
     uint32_t phase = 0;
     if (cl != ch) {
-        int dx = (int)(ch % (uint32_t)g.gw) - (int)(cl % (uint32_t)g.gw);
-        int dy = (int)(ch / (uint32_t)g.gw) - (int)(cl / (uint32_t)g.gw);
+        uint32_t xl = g.body[lo].cxy, xh = g.body[hi].cxy;
+        int dx = (int)(xh & 0xffffu) - (int)(xl & 0xffffu);
+        int dy = (int)(xh >> 16) - (int)(xl >> 16);
         phase = neighbour_phase(dy, dx);
     }
     return make_pair_key(g, cl, phase, a, b);
@@ -491,8 +500,8 @@ PSIM_HD PSIM_FORCEINLINE bool in_contact(vec2 pi, vec2 pj, int32_t ri, int32_t r
 {
     double dx = pj.x - pi.x, dy = pj.y - pi.y;
     double d2 = dx * dx + dy * dy;
-    int64_t md = (int64_t)ri + (int64_t)rj;
-    return d2 < (double)(md * md) && d2 > 0;
+    double md = (double)(ri + rj);       // (ri + rj)^2 is exact in FP64 for radii below 2^25
+    return d2 < md * md && d2 > 0;
 }
 
 PSIM_HD PSIM_FORCEINLINE vec2 body_pos(const CellBody& b) { vec2 v; v.x = b.x; v.y = b.y; return v; }
@@ -502,8 +511,8 @@ PSIM_HD PSIM_FORCEINLINE vec2 body_pos(const CellBody& b) { vec2 v; v.x = b.x; v
 template <class F>
 PSIM_HD PSIM_FORCEINLINE void for_each_neighbour_slot(const GridView& g, uint32_t k, F f)
 {
-    uint32_t c = g.body[k].cell;
-    int cx = (int)(c % (uint32_t)g.gw), cy = (int)(c / (uint32_t)g.gw);
+    uint32_t c = g.body[k].cell, cxy = g.body[k].cxy;
+    int cx = (int)(cxy & 0xffffu), cy = (int)(cxy >> 16);
     for (int32_t b = g.offsets[c]; b < g.offsets[c + 1]; ++b)
         if ((uint32_t)b != k) f((uint32_t)b);
     for (int dy = -1; dy <= 1; ++dy)
@@ -529,7 +538,8 @@ PSIM_HD PSIM_FORCEINLINE void for_each_slot_in_cell(const GridView& g, uint32_t 
     }
     int idx = which - 1;
     if (idx == 4) return;
-    int cx = (int)(c % (uint32_t)g.gw), cy = (int)(c / (uint32_t)g.gw);
+    uint32_t cxy = g.body[k].cxy;
+    int cx = (int)(cxy & 0xffffu), cy = (int)(cxy >> 16);
     int nx = cx + (idx % 3 - 1), ny = cy + (idx / 3 - 1);
     if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) return;
     uint32_t nc = (uint32_t)(ny * g.gw + nx);
@@ -550,6 +560,10 @@ struct ContactDetect {
     uint64_t* out_keys;        // pass 1
     int32_t write_pass;
     uint32_t* cand_counter;    // optional (pass 0): number of candidate pairs
+    // Every unordered candidate pair is examined once: in-cell pairs from the earlier
+    // slot, cross-cell pairs from the cell that has the other one among its four
+    // "forward" neighbours (E, SW, S, SE).  A contact is keyed from its lower-index
+    // particle, whichever side found it.
     template <bool WRITE>
     PSIM_HD PSIM_FORCEINLINE void run(uint32_t k) const
     {
@@ -557,7 +571,7 @@ struct ContactDetect {
         uint32_t p = me.idx, c = me.cell;
         uint32_t a = k - (uint32_t)g.offsets[c];
         vec2 P = body_pos(me);
-        int cx = (int)(c % (uint32_t)g.gw), cy = (int)(c / (uint32_t)g.gw);
+        int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
         uint32_t ncand = 0, found = 0;
         uint32_t at = WRITE ? offsets[k] : 0u;
         for (int32_t b = (int32_t)k + 1; b < g.offsets[c + 1]; ++b) {
@@ -568,24 +582,25 @@ struct ContactDetect {
                 ++found;
             }
         }
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                if (dx == 0 && dy == 0) continue;
-                int nx = cx + dx, ny = cy + dy;
-                if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) continue;
-                uint32_t nc = (uint32_t)(ny * g.gw + nx);
-                int32_t o0 = g.offsets[nc];
-                for (int32_t b = o0; b < g.offsets[nc + 1]; ++b) {
-                    const CellBody o = g.body[b];
-                    if (o.idx > p) {
-                        ++ncand;
-                        if (in_contact(P, body_pos(o), me.r, o.r)) {
-                            if (WRITE) out_keys[at + found] = make_pair_key(g, c, neighbour_phase(dy, dx), a, (uint32_t)(b - o0));
-                            ++found;
-                        }
-                    }
+        for (int f = 0; f < 4; ++f) {
+            int dx = (f == 0) ? 1 : f - 2, dy = (f == 0) ? 0 : 1;
+            int nx = cx + dx, ny = cy + dy;
+            if (nx < 0 || nx >= g.gw || ny >= g.gh) continue;
+            uint32_t nc = (uint32_t)(ny * g.gw + nx);
+            int32_t o0 = g.offsets[nc];
+            for (int32_t b = o0; b < g.offsets[nc + 1]; ++b) {
+                const CellBody o = g.body[b];
+                ++ncand;
+                bool lower = p < o.idx;
+                bool hit = lower ? in_contact(P, body_pos(o), me.r, o.r) : in_contact(body_pos(o), P, o.r, me.r);
+                if (hit) {
+                    if (WRITE)
+                        out_keys[at + found] = lower ? make_pair_key(g, c, neighbour_phase(dy, dx), a, (uint32_t)(b - o0))
+                                                     : make_pair_key(g, nc, neighbour_phase(-dy, -dx), (uint32_t)(b - o0), a);
+                    ++found;
                 }
             }
+        }
         if (!WRITE) {
             counts[k] = found;
             if (cand_counter && ncand) atomic_inc_u32(cand_counter, ncand);
@@ -908,16 +923,8 @@ struct GatherThermal {
     int64_t n;
     const CellBody* body;
     const double* temp;
-    const double* mass;
-    vec2* ctm;                // slot -> {temperature, mass}
-    PSIM_HD void operator()(int64_t k) const
-    {
-        uint32_t p = body[k].idx;
-        vec2 v;
-        v.x = temp[p];
-        v.y = mass[p];
-        ctm[k] = v;
-    }
+    double* ctemp;            // slot -> temperature
+    PSIM_HD void operator()(int64_t k) const { ctemp[k] = temp[body[k].idx]; }
 };
 
 // particle_system.py:271-336 as a per-particle gather (Jacobi: reads the
@@ -927,7 +934,8 @@ struct GatherThermal {
 struct Conduction {
     int64_t n;
     GridView g;
-    const vec2* ctm;
+    const double* ctemp;
+    const double* mass;       // index space (own mass only)
     double heat_coeff;
     double cool_factor;       // 1 - damping
     int32_t do_conduct, do_cool;
@@ -940,17 +948,17 @@ struct Conduction {
         uint32_t k = (uint32_t)(k0 + kk);
         const CellBody me = g.body[k];
         uint32_t p = me.idx;
-        double T = ctm[k].x;
+        double T = ctemp[k];
         double delta = 0.0;
         if (do_conduct) {
-            double m = ctm[k].y;
+            double m = mass[p];
             for_each_neighbour_slot(g, k, [&](uint32_t y) {
                 const CellBody o = g.body[y];
                 double dx = o.x - me.x, dy = o.y - me.y;
                 double d2 = dx * dx + dy * dy;
-                int64_t cd = (int64_t)me.r + (int64_t)o.r;
-                if (d2 < (double)(cd * cd)) {
-                    double Tq = ctm[y].x;
+                double cd = (double)(me.r + o.r);
+                if (d2 < cd * cd) {
+                    double Tq = ctemp[y];
                     if (p < o.idx) {
                         double diff = T - Tq;
                         if (diff != 0) delta -= (heat_coeff * diff) / m;

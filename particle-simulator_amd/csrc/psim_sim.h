@@ -96,7 +96,7 @@ public:
     DevBuf<uint32_t> ckey[2], cperm[2];
     DevBuf<int32_t> offsets;
     DevBuf<CellBody> cbody;
-    DevBuf<vec2> ctm;
+    DevBuf<double> ctemp;
     DevBuf<int32_t> cseg;
     bool cseg_ready = false;
 
@@ -131,11 +131,14 @@ public:
     int64_t solver_rounds = 0, solver_fixpoint_iters = 0;
     bool count_walk = false;
     be::StageTimer timer;
+    static constexpr size_t kPinnedBytes = 4096;
+    void* pinned = nullptr;
 
-    ~Sim() { timer.destroy(); }
+    ~Sim() { timer.destroy(); be::host_free_pinned(pinned); }
 
     explicit Sim(const Config& c) : cfg(c), st(0)
     {
+        pinned = be::host_alloc_pinned(kPinnedBytes);
         counters.ensure(16);
         red_tmp.ensure(be::kReduceBlocks);
         red_out.ensure(8);
@@ -148,6 +151,7 @@ public:
     {
         if (c.grid_w <= 0 || c.grid_h <= 0 || c.cell_size <= 0) throw std::invalid_argument("psim: bad grid geometry");
         if ((uint64_t)c.grid_w * (uint64_t)c.grid_h > kMaxCells) throw std::invalid_argument("psim: too many grid cells");
+        if (c.grid_w > kMaxGridDim || c.grid_h > kMaxGridDim) throw std::invalid_argument("psim: grid dimension above 65535 cells");
         if (!(c.bounds_w > 0) || !(c.bounds_h > 0)) throw std::invalid_argument("psim: bounds must be positive");
         bool geometry_changed = (c.grid_w != cfg.grid_w || c.grid_h != cfg.grid_h || c.cell_size != cfg.cell_size);
         cfg = c;
@@ -204,11 +208,18 @@ public:
         be::sync(st);
     }
 
+    // small synchronous readback through the page-locked staging block
+    void readback(void* dst, const void* dev, size_t bytes)
+    {
+        if (bytes > kPinnedBytes) throw std::runtime_error("psim: internal: readback too large");
+        be::copy_d2h(st, pinned, dev, bytes);
+        be::sync(st);
+        memcpy(dst, pinned, bytes);
+    }
     uint32_t read_u32(const uint32_t* d)
     {
         uint32_t v = 0;
-        be::copy_d2h(st, &v, d, 4);
-        be::sync(st);
+        readback(&v, d, 4);
         return v;
     }
 
@@ -251,7 +262,7 @@ public:
         offsets.ensure(cells + 1);
         be::launch(st, n + 1, SegmentOffsets{n, ckey[sorted_ckey].p, offsets.p, (uint32_t)cells});
         cbody.ensure(c);
-        be::launch(st, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pos.p, radii.p, cbody.p});
+        be::launch(st, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pos.p, radii.p, cbody.p, cfg.grid_w});
         tree_n = n;
     }
 
@@ -292,8 +303,7 @@ public:
             uint32_t* dv[2] = {node_id[0].p, node_id[1].p};
             int sd = be::radix_sort_pairs<uint32_t>(st, dk, dv, (uint64_t)m, 0, 8, sort_tmp.p);
             be::launch(st, (int64_t)m + 1, SegmentOffsets{(int64_t)m, node_depth[sd].p, depth_off.p, (uint32_t)(kKeyLevels + 1)});
-            be::copy_d2h(st, depth_off_host, depth_off.p, sizeof(int32_t) * (kKeyLevels + 2));
-            be::sync(st);
+            readback(depth_off_host, depth_off.p, sizeof(int32_t) * (kKeyLevels + 2));
             for (int d = kMaxInternalDepth; d >= 0; --d) {
                 int64_t cnt = depth_off_host[d + 1] - depth_off_host[d];
                 if (cnt <= 0) continue;
@@ -354,10 +364,9 @@ public:
             d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? counters.p + 1 : nullptr;
             be::launch(st, n, d);
             be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)n, scan_tmp.p, counters.p);
-            be::launch(st, cells, MaxOccupancy{cells, offsets.p, counters.p + 2});
+            be::launch(st, (cells + 63) / 64 * 64, MaxOccupancy{cells, offsets.p, counters.p + 2});
             uint32_t three[3];
-            be::copy_d2h(st, three, counters.p, 12);
-            be::sync(st);
+            readback(three, counters.p, 12);
             n0 = three[0]; cand = three[1];
             slot_bits = ceil_log2_u64((uint64_t)three[2] + 1);
             if (slot_bits < 1) slot_bits = 1;
@@ -484,8 +493,7 @@ public:
         be::launch(st, 2ll * nH, f);
         be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
         double t[3];
-        be::copy_d2h(st, t, red_out.p, 24);
-        be::sync(st);
+        readback(t, red_out.p, 24);
         coll_totals[0] += t[0]; coll_totals[1] += t[1]; coll_totals[2] += t[2];
         n_contacts += nH;
         if (cfg.debug) log_n += nH;
@@ -504,13 +512,13 @@ public:
             return;
         }
         size_t c = (size_t)n;
-        ctm.ensure(c);
+        ctemp.ensure(c);
         GridView g = grid_view();
-        be::launch(st, n, GatherThermal{n, cbody.p, temp.p, mass.p, ctm.p});
+        be::launch(st, n, GatherThermal{n, cbody.p, temp.p, ctemp.p});
         if (cfg.debug) delta_dbg.ensure(c);
         if (hi <= lo) return;
         Conduction k;
-        k.n = hi - lo; k.g = g; k.ctm = ctm.p;
+        k.n = hi - lo; k.g = g; k.ctemp = ctemp.p; k.mass = mass.p;
         k.heat_coeff = cfg.heat_coeff; k.cool_factor = factor; k.do_conduct = 1; k.do_cool = cool ? 1 : 0;
         k.temp = temp.p; k.temp_slots = temp_slots; k.delta_out = cfg.debug ? delta_dbg.p : nullptr; k.k0 = lo;
         be::launch(st, hi - lo, k);
@@ -697,8 +705,7 @@ public:
         if (tree_valid && n_internal > 0) be::reduce_sum_f64(st, pe_node.p, n_internal, red_tmp.p, red_out.p + 4);
         else be::dev_memset(st, red_out.p + 4, 0, 8);
         double t[5];
-        be::copy_d2h(st, t, red_out.p, 40);
-        be::sync(st);
+        readback(t, red_out.p, 40);
         out5[0] = t[0]; out5[1] = t[4]; out5[2] = t[1]; out5[3] = t[2]; out5[4] = t[3];
     }
 };

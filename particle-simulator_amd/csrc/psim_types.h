@@ -35,7 +35,7 @@ struct alignas(32) CellBody {
     int32_t r;
     uint32_t idx;
     uint32_t cell;
-    uint32_t pad;
+    uint32_t cxy;      // cell column | cell row << 16
 };
 
 constexpr uint32_t kLeaf = 255;
@@ -45,6 +45,7 @@ constexpr int kMaxInternalDepth = 31;   // children of depth-31 nodes are bucket
 // ordering key of a candidate pair inside one collision sweep
 // (cell | phase:4 | a | b, field widths chosen per step), see make_pair_key()
 constexpr uint32_t kMaxCells = 1u << 24;
+constexpr int32_t kMaxGridDim = 65535;   // cell column / row must fit 16 bits (CellBody::cxy)
 
 enum StageBits : int32_t {
     kStageCollisions = 1,
