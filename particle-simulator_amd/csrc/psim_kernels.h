@@ -143,7 +143,7 @@ struct MaxOccupancy {
             uint32_t t = (uint32_t)__shfl_xor((int)occ, o, 64);
             occ = t > occ ? t : occ;
         }
-        if ((threadIdx.x & 63u) == 0u) atomicMax(out, occ);
+        if ((threadIdx.x & 63u) == 0u && occ > *((volatile uint32_t*)out)) atomicMax(out, occ);
 #endif
     }
 };
@@ -182,6 +182,51 @@ struct GatherTree {
         uint32_t p = perm[s];
         spos[s] = pos[p];
         smass[s] = mass[p];
+    }
+};
+
+// Second half of the Morton sort.  The radix passes order the keys by their high
+// 32 bits only (the 16 coarsest levels); particles that share those are rare and
+// form short runs, which the lane at each run's start finishes by ranking on the
+// full key (ties keep input order, like the stable radix passes).  A run longer
+// than kMaxFixRun is copied as is and reported, and the caller completes the sort
+// with the remaining radix passes.
+constexpr uint32_t kMaxFixRun = 48;
+struct FixRuns {
+    int64_t n;
+    const uint64_t* key_in;
+    const uint32_t* perm_in;
+    uint64_t* key_out;
+    uint32_t* perm_out;
+    uint32_t* overflow;
+    PSIM_HD void operator()(int64_t s) const
+    {
+        uint64_t k0 = key_in[s];
+        uint32_t hi = (uint32_t)(k0 >> 32);
+        if (s > 0 && (uint32_t)(key_in[s - 1] >> 32) == hi) return;
+        int64_t e = s + 1;
+        while (e < n && (uint32_t)(key_in[e] >> 32) == hi) ++e;
+        int64_t r = e - s;
+        if (r == 1) {
+            key_out[s] = k0;
+            perm_out[s] = perm_in[s];
+            return;
+        }
+        if (r > (int64_t)kMaxFixRun) {
+            for (int64_t i = s; i < e; ++i) { key_out[i] = key_in[i]; perm_out[i] = perm_in[i]; }
+            *overflow = 1u;
+            return;
+        }
+        for (int64_t i = s; i < e; ++i) {
+            uint64_t ki = key_in[i];
+            int64_t rank = 0;
+            for (int64_t j = s; j < e; ++j) {
+                uint64_t kj = key_in[j];
+                rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+            }
+            key_out[s + rank] = ki;
+            perm_out[s + rank] = perm_in[i];
+        }
     }
 };
 
@@ -771,6 +816,35 @@ PSIM_HD PSIM_FORCEINLINE vec2 versioned_pos(uint32_t slot, uint64_t t, const int
     return out[2 * last + side].pos;
 }
 
+// For each touched slot: how far any of its versioned positions lies from its
+// initial one (inflated so that rounding can never make the bound too small).
+// Stored at the slot's first adjacency entry.  Lets the re-test discard, exactly,
+// neighbours that no version could reach.
+struct SegDisplacement {
+    int64_t n_adj;
+    const uint64_t* adj;
+    const int32_t* cseg;
+    const uint32_t* hsi;
+    const BodyState* out;
+    const CellBody* body;
+    double* dseg;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t x = (uint32_t)(adj[e] >> 32);
+        if (cseg[x] != (int32_t)e) return;
+        double x0 = body[x].x, y0 = body[x].y, m = 0.0;
+        for (int64_t k = e; k < n_adj && (uint32_t)(adj[k] >> 32) == x; ++k) {
+            uint32_t h = (uint32_t)adj[k];
+            int side = (hsi[h] == x) ? 0 : 1;
+            vec2 p = out[2 * h + side].pos;
+            double dx = p.x - x0, dy = p.y - y0;
+            double d2 = dx * dx + dy * dy;
+            m = d2 > m ? d2 : m;
+        }
+        dseg[e] = sqrt(m) * (1.0 + 1e-6) + 1e-9;
+    }
+};
+
 // Re-test, against the versioned positions, every candidate pair that involves
 // a slot touched by a hypothesised contact.  Element index = adjacency entry *
 // 10 + cell selector (the nine cells of one touched slot are re-tested by
@@ -785,6 +859,7 @@ struct ContactRetest {
     const uint64_t* hkeys;
     const uint32_t* hsi;
     const BodyState* out;
+    const double* dseg;
     uint32_t* counts;
     const uint32_t* offsets;
     uint64_t* out_keys;
@@ -797,13 +872,22 @@ struct ContactRetest {
         uint32_t x = (uint32_t)(adj[e] >> 32);
         uint32_t found = 0;
         if (cseg[x] == (int32_t)e) {
-            uint32_t px = g.body[x].idx;
-            int32_t rx = g.body[x].r;
+            const CellBody bx = g.body[x];
+            uint32_t px = bx.idx;
+            int32_t rx = bx.r;
+            double reach_x = dseg[e];
             uint32_t at = write_pass ? offsets[t] : 0u;
             for_each_slot_in_cell(g, x, which, [&](uint32_t y) {
-                uint32_t py = g.body[y].idx;
-                int32_t ry = g.body[y].r;
-                if (cseg[y] >= 0 && py < px) return;       // y's own pass emits it
+                const CellBody by = g.body[y];
+                uint32_t py = by.idx;
+                int32_t ry = by.r;
+                int32_t sy = cseg[y];
+                // no version of x and y can touch if their initial positions are further
+                // apart than the contact distance plus both displacement bounds
+                double reach = (double)(rx + ry) + reach_x + (sy >= 0 ? dseg[sy] : 0.0);
+                double ddx = by.x - bx.x, ddy = by.y - bx.y;
+                if (ddx * ddx + ddy * ddy > reach * reach) return;
+                if (sy >= 0 && py < px) return;       // y's own pass emits it
                 uint64_t tk = pair_key(g, x, y);
                 vec2 X = versioned_pos(x, tk, cseg, adj, n_adj, hkeys, hsi, out, g.body);
                 vec2 Y = versioned_pos(y, tk, cseg, adj, n_adj, hkeys, hsi, out, g.body);
@@ -839,6 +923,26 @@ struct ContactCarryClean {
         uint32_t si, sj;
         decode_pair_key(g, h0keys[h], &si, &sj);
         counts[h] = (cseg[si] < 0 && cseg[sj] < 0) ? 1u : 0u;
+    }
+};
+
+// every key of `a` occurs in the sorted, duplicate-free list `b` (binary search);
+// with equal lengths and duplicate-free `a` that makes the two lists equal as sets
+struct AllFound {
+    int64_t n;
+    const uint64_t* a;
+    const uint64_t* b;
+    int64_t nb;
+    uint32_t* missing;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        uint64_t key = a[i];
+        int64_t lo = 0, hi = nb;
+        while (lo < hi) {
+            int64_t mid = lo + (hi - lo) / 2;
+            if (b[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        if (!(lo < nb && b[lo] == key)) aggregated_inc(missing);
     }
 };
 

@@ -106,7 +106,7 @@ public:
     DevBuf<uint32_t> hsi, hsj, done, pcount, poffs;
     DevBuf<int32_t> prevl;
     DevBuf<BodyState> outst;
-    DevBuf<double> cvals, sum_pe, sum_ke, sum_heat;
+    DevBuf<double> cvals, sum_pe, sum_ke, sum_heat, dseg;
     DevBuf<int32_t> log_ij;
     DevBuf<double> log_vals, delta_dbg;
     int64_t log_n = 0;
@@ -276,15 +276,37 @@ public:
         sort_tmp.ensure(be::sort_temp_words(c));
         uint64_t* k[2] = {key[0].p, key[1].p};
         uint32_t* v[2] = {perm[0].p, perm[1].p};
-        sorted_key = be::radix_sort_pairs<uint64_t>(st, k, v, (uint64_t)n, 0, 64, sort_tmp.p);
-        const uint64_t* skey = key[sorted_key].p;
-        const uint32_t* sperm = perm[sorted_key].p;
         spos.ensure(c); smass.ensure(c); L.ensure(c); owned.ensure(c); base.ensure(c);
-        be::launch(st, n, GatherTree{n, sperm, pos.p, mass.p, spos.p, smass.p});
-        be::launch(st, n, TreeLinks{n, skey, L.p, owned.p});
         scan_tmp.ensure(be::scan_temp_words(c));
-        be::exclusive_scan_u32(st, owned.p, base.p, (uint64_t)n, scan_tmp.p, counters.p);
-        uint32_t m = read_u32(counters.p);
+        uint32_t m = 0;
+        const uint64_t* skey = nullptr;
+        const uint32_t* sperm = nullptr;
+        for (int attempt = 0;; ++attempt) {
+            if (attempt == 0) {
+                // radix passes on the high 32 bits, then FixRuns orders the (rare, short) runs
+                // of particles that share them
+                int half = be::radix_sort_pairs<uint64_t>(st, k, v, (uint64_t)n, 32, 64, sort_tmp.p);
+                be::dev_memset(st, counters.p + 4, 0, 4);
+                be::launch(st, n, FixRuns{n, key[half].p, perm[half].p, key[half ^ 1].p, perm[half ^ 1].p, counters.p + 4});
+                sorted_key = half ^ 1;
+            } else {
+                // a long run of near-coincident particles was left unsorted: full LSD sort
+                uint64_t* k2[2] = {key[sorted_key].p, key[sorted_key ^ 1].p};
+                uint32_t* v2[2] = {perm[sorted_key].p, perm[sorted_key ^ 1].p};
+                int r = be::radix_sort_pairs<uint64_t>(st, k2, v2, (uint64_t)n, 0, 64, sort_tmp.p);
+                sorted_key = sorted_key ^ r;
+            }
+            skey = key[sorted_key].p;
+            sperm = perm[sorted_key].p;
+            be::launch(st, n, GatherTree{n, sperm, pos.p, mass.p, spos.p, smass.p});
+            be::launch(st, n, TreeLinks{n, skey, L.p, owned.p});
+            be::exclusive_scan_u32(st, owned.p, base.p, (uint64_t)n, scan_tmp.p, counters.p);
+            uint32_t five[5];
+            readback(five, counters.p, 20);      // [0] internal nodes, [4] FixRuns overflow
+            m = five[0];
+            if (attempt == 0 && five[4] != 0) continue;
+            break;
+        }
         // the reference's pool holds 4N+1 nodes = at most N subdivided cells (quadtree.py:165)
         if ((uint64_t)m > (uint64_t)n) throw std::runtime_error("psim: quadtree node pool overflow (near-coincident particles)");
         n_internal = m;
@@ -426,8 +448,11 @@ public:
                 int64_t nt = 20ll * nH, ntot = nt + n0;
                 pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot);
                 scan_tmp.ensure(be::scan_temp_words((uint64_t)ntot));
+                dseg.ensure(2 * (size_t)nH);
+                be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p});
                 ContactRetest r;
                 r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outst.p;
+                r.dseg = dseg.p;
                 r.counts = pcount.p; r.offsets = poffs.p; r.out_keys = nullptr;
                 r.write_pass = 0;
                 ContactCarryClean cc{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
@@ -449,15 +474,17 @@ public:
                     be::launch(st, n0, cc);
                 }
             }
-            uint64_t* kn[2] = {hn[0].p, hn[1].p};
-            hn_which = be::radix_sort_pairs<uint64_t>(st, kn, nullptr, nNew, 0, key_bits, sort_tmp.p);
+            // H' == H?  Both are duplicate-free, so equal length + every new key found in the
+            // (sorted) hypothesis means equal sets; the new list is only sorted if it is needed.
             bool same = (nNew == nH);
             if (same) {
                 be::dev_memset(st, counters.p, 0, 4);
-                be::launch(st, nH, CompareKeys{(int64_t)nH, H, hn[hn_which].p, counters.p});
+                be::launch(st, nNew, AllFound{(int64_t)nNew, hn[0].p, H, (int64_t)nH, counters.p});
                 same = read_u32(counters.p) == 0;
             }
             if (same) break;
+            uint64_t* kn[2] = {hn[0].p, hn[1].p};
+            hn_which = be::radix_sort_pairs<uint64_t>(st, kn, nullptr, nNew, 0, key_bits, sort_tmp.p);
             be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
             be::copy_d2d(st, hc[0].p, hn[hn_which].p, (size_t)nNew * 8);
             nH = nNew;

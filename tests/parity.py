@@ -128,3 +128,21 @@ def run_against_oracle(n, sim, seed, bounds, steps, library, walk_mode=0, state=
     np.testing.assert_allclose(e_s, e_o, rtol=1e-8)
     s.close()
     return s, o
+
+
+def clustered_state(n, bounds, seed, clusters, per, spread):
+    """uniform particles plus `clusters` knots of `per` particles within `spread`
+    pixels of each other (they share all coarse quadtree levels: deep chains,
+    long runs of equal high key bits, contact chains)"""
+    rng = np.random.default_rng(seed)
+    pos = rng.random((n, 2)) * np.array(bounds)
+    masses = rng.uniform(5.0, 20.0, (n, 1))
+    temps = rng.uniform(0.05, 0.1, (n, 1))
+    k = 0
+    for c in range(clusters):
+        centre = rng.random(2) * (np.array(bounds) - 40) + 20
+        for j in range(per):
+            pos[k] = centre + rng.random(2) * spread
+            k += 1
+    perm = rng.permutation(n)          # knots scattered through the index space
+    return dict(positions=pos[perm], masses=masses[perm], temperatures=temps[perm])

@@ -94,3 +94,13 @@ def test_sharded_step_over_rccl_single_rank():
     from test_distributed_gloo import run_ranks
     run_ranks(1, "nccl", "hip", "dense256", 6)
     run_ranks(1, "nccl", "hip", "hot300", 6)
+
+
+@pytest.mark.parametrize("clusters,per,spread", [(12, 3, 1e-3), (2, 70, 2e-3), (4, 20, 2e-5)])
+def test_near_coincident_knots_vs_oracle(clusters, per, spread):
+    """knots of particles sharing the 16 coarsest quadtree levels: run fix-up of the
+    Morton sort (short runs; runs long enough to fall back to the full radix sort),
+    deep single-child chains, contact chains"""
+    n, bounds = 3000, (1500, 900)
+    st = parity.clustered_state(n, bounds, 77, clusters, per, spread)
+    parity.run_against_oracle(n, SIM, 1, bounds, 3, HIP, state=st)

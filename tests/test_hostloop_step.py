@@ -37,3 +37,19 @@ def test_tree_gravity_20k():
     parity.check_tree(s, g, "init_")
     parity.acc_close(s.accelerations, g["prime_accelerations"])
     np.testing.assert_allclose(s.get_energies()[1], g["prime_energies"][1], rtol=1e-11)
+
+
+SIM = dict(min_mass=5.0, max_mass=20.0, gravity_constant=0.01, softening_factor=10, barnes_hut_theta=0.5,
+           min_temp=0.05, max_temp=0.1, heat_transfer_coefficient=0.1, coefficient_of_restitution=0.5,
+           grid_cell_size_multiplier=10.0, position_correction_factor=1.05, collision_solver_iterations=1,
+           explosion_efficiency=0.5, thermal_damping_factor=0.0005)
+
+
+@pytest.mark.parametrize("clusters,per,spread", [(12, 3, 1e-3), (2, 70, 2e-3), (4, 20, 2e-5)])
+def test_near_coincident_knots_vs_oracle(clusters, per, spread):
+    """knots of particles that share the 16 coarsest quadtree levels: exercises the
+    run fix-up of the Morton sort (short runs, and runs long enough to fall back to
+    the full radix sort), deep chains of single-child nodes and contact chains"""
+    n, bounds = 3000, (1500, 900)
+    st = parity.clustered_state(n, bounds, 77, clusters, per, spread)
+    parity.run_against_oracle(n, SIM, 1, bounds, 3, HOSTLOOP, walk_mode=1, state=st)
