@@ -458,8 +458,10 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
             ay = fma(f, dy, ay);
             until = jb;
         }
-        const bool open = active && !take && !leaf;
-        ju = (__builtin_amdgcn_ballot_w64(open) != 0ull) ? ja : jb;
+        // a lane still wants this node's children iff it was active and did not accept, i.e.
+        // its park index is still <= the cursor (accepting lanes just moved theirs past it)
+        const bool descend = !leaf && (__builtin_amdgcn_ballot_w64(until <= ju) != 0ull);
+        ju = descend ? ja : jb;
     }
     if (live) {
         uint32_t p = perm[s];

@@ -143,7 +143,8 @@ struct MaxOccupancy {
             uint32_t t = (uint32_t)__shfl_xor((int)occ, o, 64);
             occ = t > occ ? t : occ;
         }
-        if ((threadIdx.x & 63u) == 0u && occ > *((volatile uint32_t*)out)) atomicMax(out, occ);
+        // L2-served relaxed read: a stale value only costs a redundant atomic
+        if ((threadIdx.x & 63u) == 0u && occ > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, occ);
 #endif
     }
 };
