@@ -340,10 +340,11 @@ struct TreeCom {
     NodeRec* rec;
     double* pe_node;
     double g_const, softening;
-    PSIM_HD void operator()(int64_t t) const
+    // deepest level only: children are the four depth-32 cells, each a bucket of
+    // particles that coincide to all 32 levels (the reference never terminates on these)
+    PSIM_HD void children_by_search(uint32_t id, uint32_t s, double* cm, double* cx, double* cy) const
     {
-        uint32_t id = ids[t];
-        uint32_t s = node_first[id], e = node_last[id];
+        uint32_t e = node_last[id];
         int sh = 62 - 2 * depth;
         // quadrant boundaries inside [s, e]
         uint32_t bnd[5];
@@ -357,7 +358,6 @@ struct TreeCom {
             }
             bnd[q] = lo;
         }
-        double cm[4], cx[4], cy[4];
         for (int q = 0; q < 4; ++q) {
             uint32_t c0 = bnd[q], cnt = bnd[q + 1] - bnd[q];
             cm[q] = 0.0; cx[q] = 0.0; cy[q] = 0.0;
@@ -381,6 +381,28 @@ struct TreeCom {
                     if (tm > 0) { cx[q] = nx / tm; cy[q] = ny / tm; }
                 }
             }
+        }
+    }
+
+    PSIM_HD void operator()(int64_t t) const
+    {
+        uint32_t id = ids[t];
+        uint32_t s = node_first[id];
+        double cm[4], cx[4], cy[4];
+        for (int q = 0; q < 4; ++q) { cm[q] = 0.0; cx[q] = 0.0; cy[q] = 0.0; }
+        if (depth < kMaxInternalDepth) {
+            // the children are the elements of this node's subtree reached by following skip
+            // from its first element: pre-order = quadrant order, empty quadrants absent
+            uint32_t end = rec[s + id].skip;
+            uint32_t c = s + id + 1;
+            for (int q = 0; q < 4 && c < end; ++q) {
+                const NodeRec& r = rec[c];
+                cm[q] = r.mass; cx[q] = r.x; cy[q] = r.y;
+                uint32_t nxt = r.skip;
+                c = nxt > c ? nxt : c + 1;
+            }
+        } else {
+            children_by_search(id, s, cm, cx, cy);
         }
         double total = 0.0, nx = 0.0, ny = 0.0;
         for (int q = 0; q < 4; ++q) {

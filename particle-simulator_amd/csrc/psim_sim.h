@@ -423,12 +423,12 @@ public:
             int sa = be::radix_sort_pairs<uint64_t>(st, ka, nullptr, 2ull * nH, 32, 32 + slot_field_bits, sort_tmp.p);
             adjs = adj[sa].p;
             be::launch(st, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p});
-            // rounds are launched four at a time between reads of the running count
+            // rounds are launched six at a time between reads of the running count
             // (a round with nothing ready is a no-op)
             uint32_t executed = 0, round = 0;
             be::dev_memset(st, counters.p, 0, 4);
             while (executed < nH) {
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < 6; ++b) {
                     ++round;
                     ContactSimulate s;
                     s.n = nH; s.hsi = hsi.p; s.hsj = hsj.p; s.prev = prevl.p; s.done = done.p; s.round = round;
@@ -438,7 +438,7 @@ public:
                     be::launch(st, nH, s);
                 }
                 uint32_t ex = read_u32(counters.p);
-                solver_rounds += 4;
+                solver_rounds += 6;
                 if (ex <= executed || ex > nH) throw std::runtime_error("psim: internal: contact schedule stalled");
                 executed = ex;
             }
