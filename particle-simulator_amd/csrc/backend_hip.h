@@ -363,6 +363,25 @@ __global__ void __launch_bounds__(256) reduce_partial_kernel(const double* in, u
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
 }
 
+// three short arrays summed in one launch (one 256-lane block each, fixed association)
+__global__ void __launch_bounds__(256) reduce3_small_kernel(const double* a, const double* b, const double* c,
+                                                            uint64_t n, double* out3)
+{
+    __shared__ double s[256];
+    const double* in = blockIdx.x == 0 ? a : blockIdx.x == 1 ? b : c;
+    double acc = 0.0;
+    for (uint64_t i = threadIdx.x; i < n; i += 256) acc += in[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out3[blockIdx.x] = s[0];
+}
+inline void reduce3_sum_f64(Stream st, const double* a, const double* b, const double* c, uint64_t n, double* temp,
+                            double* out3);
+
 // temp: kReduceBlocks doubles.  out: device double.
 inline void reduce_sum_f64(Stream st, const double* in, uint64_t n, double* temp, double* out)
 {
@@ -376,6 +395,24 @@ inline void reduce_sum_f64(Stream st, const double* in, uint64_t n, double* temp
     PSIM_HIP(hipGetLastError());
 }
 
+}  // namespace be
+}  // namespace psim
+
+namespace psim {
+namespace be {
+inline void reduce3_sum_f64(Stream st, const double* a, const double* b, const double* c, uint64_t n, double* temp,
+                            double* out3)
+{
+    if (n == 0) { dev_memset(st, out3, 0, 24); return; }
+    if (n <= (1u << 18)) {
+        hipLaunchKernelGGL(reduce3_small_kernel, dim3(3), dim3(256), 0, st, a, b, c, n, out3);
+        PSIM_HIP(hipGetLastError());
+        return;
+    }
+    reduce_sum_f64(st, a, n, temp, out3);
+    reduce_sum_f64(st, b, n, temp, out3 + 1);
+    reduce_sum_f64(st, c, n, temp, out3 + 2);
+}
 }  // namespace be
 }  // namespace psim
 

@@ -126,25 +126,45 @@ struct SegmentOffsets {
     }
 };
 
-// largest cell population (run over cells): lanes only issue an atomic when they
-// would raise the value they just read
-struct MaxOccupancy {
+// largest cell population, in two launches without same-address atomics:
+// WaveMaxOccupancy (over cells rounded up to whole waves) stores one maximum per 64
+// cells, FinalMax (one wave) folds those.
+struct WaveMaxOccupancy {
     int64_t cells;
     const int32_t* offsets;
-    uint32_t* out;
+    uint32_t* wave_max;        // [ceil(cells / 64)]
     PSIM_HD void operator()(int64_t c) const
     {
-        // launched over `cells` rounded up to a multiple of 64, so whole waves are active
         uint32_t occ = c < cells ? (uint32_t)(offsets[c + 1] - offsets[c]) : 0u;
 #if defined(PSIM_HOSTLOOP)
-        if (occ > *out) *out = occ;
+        if ((c & 63) == 0) wave_max[c >> 6] = 0;
+        if (occ > wave_max[c >> 6]) wave_max[c >> 6] = occ;
 #else
-        for (int o = 32; o > 0; o >>= 1) {      // wave maximum
+        for (int o = 32; o > 0; o >>= 1) {
             uint32_t t = (uint32_t)__shfl_xor((int)occ, o, 64);
             occ = t > occ ? t : occ;
         }
-        // L2-served relaxed read: a stale value only costs a redundant atomic
-        if ((threadIdx.x & 63u) == 0u && occ > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, occ);
+        if ((c & 63) == 0) wave_max[c >> 6] = occ;
+#endif
+    }
+};
+struct FinalMax {          // launched over exactly 64 elements
+    int64_t count;
+    const uint32_t* wave_max;
+    uint32_t* out;
+    PSIM_HD void operator()(int64_t lane) const
+    {
+        uint32_t m = 0;
+        for (int64_t i = lane; i < count; i += 64) { uint32_t v = wave_max[i]; m = v > m ? v : m; }
+#if defined(PSIM_HOSTLOOP)
+        if (lane == 0) *out = 0;
+        if (m > *out) *out = m;
+#else
+        for (int o = 32; o > 0; o >>= 1) {
+            uint32_t t = (uint32_t)__shfl_xor((int)m, o, 64);
+            m = t > m ? t : m;
+        }
+        if (lane == 0) *out = m;
 #endif
     }
 };
@@ -818,6 +838,13 @@ struct ContactSimulate {
         done[h] = round;
         aggregated_inc(executed);
     }
+};
+
+struct CountPending {
+    int64_t n;
+    const uint32_t* done;
+    uint32_t* pending;
+    PSIM_HD void operator()(int64_t h) const { if (done[h] == 0) aggregated_inc(pending); }
 };
 
 // position of a slot as seen by the candidate pair with ordering key t: the

@@ -386,7 +386,10 @@ public:
             d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? counters.p + 1 : nullptr;
             be::launch(st, n, d);
             be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)n, scan_tmp.p, counters.p);
-            be::launch(st, (cells + 63) / 64 * 64, MaxOccupancy{cells, offsets.p, counters.p + 2});
+            int64_t cwaves = (cells + 63) / 64;
+            tmp32.ensure((size_t)cwaves);
+            be::launch(st, cwaves * 64, WaveMaxOccupancy{cells, offsets.p, tmp32.p});
+            be::launch(st, 64, FinalMax{cwaves, tmp32.p, counters.p + 2});
             uint32_t three[3];
             readback(three, counters.p, 12);
             n0 = three[0]; cand = three[1];
@@ -423,25 +426,23 @@ public:
             int sa = be::radix_sort_pairs<uint64_t>(st, ka, nullptr, 2ull * nH, 32, 32 + slot_field_bits, sort_tmp.p);
             adjs = adj[sa].p;
             be::launch(st, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p});
-            // rounds are launched six at a time between reads of the running count
-            // (a round with nothing ready is a no-op)
-            uint32_t executed = 0, round = 0;
-            be::dev_memset(st, counters.p, 0, 4);
-            while (executed < nH) {
-                for (int b = 0; b < 6; ++b) {
+            // Dependency rounds.  A first batch is launched without asking how far it got (a
+            // round with nothing ready is a no-op); whether contacts are still pending is read
+            // back together with the re-test count below, and only then are more rounds run.
+            uint32_t round = 0;
+            auto run_rounds = [&](int count) {
+                for (int b = 0; b < count; ++b) {
                     ++round;
                     ContactSimulate s;
                     s.n = nH; s.hsi = hsi.p; s.hsj = hsj.p; s.prev = prevl.p; s.done = done.p; s.round = round;
-                    s.out = outst.p; s.vals = cvals.p; s.executed = counters.p; s.body = cbody.p;
+                    s.out = outst.p; s.vals = cvals.p; s.executed = counters.p + 3; s.body = cbody.p;
                     s.vel = vel.p; s.temp = temp.p; s.mass = mass.p; s.G = cfg.gravity_constant;
                     s.soft = cfg.softening; s.restitution = cfg.restitution; s.pos_correct = cfg.pos_correct;
                     be::launch(st, nH, s);
                 }
-                uint32_t ex = read_u32(counters.p);
-                solver_rounds += 6;
-                if (ex <= executed || ex > nH) throw std::runtime_error("psim: internal: contact schedule stalled");
-                executed = ex;
-            }
+                solver_rounds += count;
+            };
+            run_rounds(6);
             // ---- re-test what the hypothesis could have changed (count, scan, write)
             uint32_t nNew = 0;
             {
@@ -456,10 +457,22 @@ public:
                 r.counts = pcount.p; r.offsets = poffs.p; r.out_keys = nullptr;
                 r.write_pass = 0;
                 ContactCarryClean cc{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
-                be::launch(st, nt, r);
-                be::launch(st, n0, cc);
-                be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)ntot, scan_tmp.p, counters.p);
-                nNew = read_u32(counters.p);
+                for (;;) {
+                    be::dev_memset(st, counters.p + 1, 0, 4);
+                    be::launch(st, nH, CountPending{(int64_t)nH, done.p, counters.p + 1});
+                    be::launch(st, nt, r);
+                    be::launch(st, n0, cc);
+                    be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)ntot, scan_tmp.p, counters.p);
+                    uint32_t two[2];
+                    readback(two, counters.p, 8);
+                    nNew = two[0];
+                    if (two[1] == 0) break;
+                    // contacts were still waiting on predecessors: the re-test above saw incomplete
+                    // versions; run further rounds and re-test again
+                    if (round > 6 + nH) throw std::runtime_error("psim: internal: contact schedule stalled");
+                    run_rounds(6);
+                    be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p});
+                }
                 if (nNew > ccap) {
                     // growing reallocates every contact buffer: restart the whole sweep
                     be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
@@ -511,9 +524,7 @@ public:
         cl.log_base = log_n; cl.log_cap = (int64_t)log_cap;
         cl.sum_pe = sum_pe.p; cl.sum_ke = sum_ke.p; cl.sum_heat = sum_heat.p;
         be::launch(st, nH, cl);
-        be::reduce_sum_f64(st, sum_pe.p, nH, red_tmp.p, red_out.p);
-        be::reduce_sum_f64(st, sum_ke.p, nH, red_tmp.p, red_out.p + 1);
-        be::reduce_sum_f64(st, sum_heat.p, nH, red_tmp.p, red_out.p + 2);
+        be::reduce3_sum_f64(st, sum_pe.p, sum_ke.p, sum_heat.p, nH, red_tmp.p, red_out.p);
         ContactFinalize f;
         f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outst.p; f.body = cbody.p;
         f.pos = pos.p; f.vel = vel.p; f.temp = temp.p;

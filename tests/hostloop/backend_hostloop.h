@@ -74,6 +74,14 @@ inline void reduce_sum_f64(Stream, const double* in, uint64_t n, double*, double
     *out = s;
 }
 
+inline void reduce3_sum_f64(Stream st, const double* a, const double* b, const double* c, uint64_t n, double* temp,
+                            double* out3)
+{
+    reduce_sum_f64(st, a, n, temp, out3);
+    reduce_sum_f64(st, b, n, temp, out3 + 1);
+    reduce_sum_f64(st, c, n, temp, out3 + 2);
+}
+
 }  // namespace be
 }  // namespace psim
 
