@@ -594,6 +594,14 @@ PSIM_HD PSIM_FORCEINLINE bool in_contact(vec2 pi, vec2 pj, int32_t ri, int32_t r
 
 PSIM_HD PSIM_FORCEINLINE vec2 body_pos(const CellBody& b) { vec2 v; v.x = b.x; v.y = b.y; return v; }
 
+// squared distance is exactly zero: no contact for the collision test (:217) but
+// "touching" for the conduction test (:322)
+PSIM_HD PSIM_FORCEINLINE bool coincident(vec2 pi, vec2 pj)
+{
+    double dx = pj.x - pi.x, dy = pj.y - pi.y;
+    return dx * dx + dy * dy == 0;
+}
+
 // Enumerate, for slot k, every slot y of the 3x3 cell neighbourhood (own cell
 // first, then neighbours in (dy, dx) order).  F(y, phase_from_k_to_y).
 template <class F>
@@ -648,6 +656,7 @@ struct ContactDetect {
     uint64_t* out_keys;        // pass 1
     int32_t write_pass;
     uint32_t* cand_counter;    // optional (pass 0): number of candidate pairs
+    uint32_t* coincident_counter;   // pass 0: pairs at squared distance exactly 0
     // Every unordered candidate pair is examined once: in-cell pairs from the earlier
     // slot, cross-cell pairs from the cell that has the other one among its four
     // "forward" neighbours (E, SW, S, SE).  A contact is keyed from its lower-index
@@ -668,6 +677,8 @@ struct ContactDetect {
             if (in_contact(P, body_pos(o), me.r, o.r)) {
                 if (WRITE) out_keys[at + found] = make_pair_key(g, c, 0, a, (uint32_t)b - (uint32_t)g.offsets[c]);
                 ++found;
+            } else if (!WRITE && coincident(P, body_pos(o))) {
+                aggregated_inc(coincident_counter);
             }
         }
         for (int f = 0; f < 4; ++f) {
@@ -686,6 +697,8 @@ struct ContactDetect {
                         out_keys[at + found] = lower ? make_pair_key(g, c, neighbour_phase(dy, dx), a, (uint32_t)(b - o0))
                                                      : make_pair_key(g, nc, neighbour_phase(-dy, -dx), (uint32_t)(b - o0), a);
                     ++found;
+                } else if (!WRITE && coincident(P, body_pos(o))) {
+                    aggregated_inc(coincident_counter);
                 }
             }
         }
@@ -1025,11 +1038,15 @@ struct ContactFinalize {
     vec2* pos;
     vec2* vel;
     double* temp;
+    uint8_t* moved;           // slot -> touched by a contact this step
+    uint32_t* newly;          // [entry] 1 where a slot is touched for the first time this step
     PSIM_HD void operator()(int64_t e) const
     {
         uint32_t x = (uint32_t)(adj[e] >> 32);
         bool last = (e + 1 == n_adj) || ((uint32_t)(adj[e + 1] >> 32) != x);
+        newly[e] = (last && moved[x] == 0) ? 1u : 0u;
         if (!last) return;
+        moved[x] = 1;
         uint32_t h = (uint32_t)adj[e];
         int side = (hsi[h] == x) ? 0 : 1;
         BodyState s = out[2 * h + side];
@@ -1146,6 +1163,94 @@ struct ScatterSlots {
     PSIM_HD void operator()(int64_t k) const { out[body[k].idx] = in_slots[k]; }
 };
 
+// ---- conduction without a second full sweep.  After the collision stage a pair of
+// slots that no contact touched is not within contact distance (it was tested against
+// the very same positions by ContactDetect, and an initial contact between untouched
+// slots would have survived into the final contact list and touched them), unless its
+// squared distance is exactly zero.  So, when no such coincident pair was seen, the
+// touching pairs of particle_system.py:322 all involve a touched slot, and conduction
+// is a sweep around the touched slots only.
+struct WriteMoved {
+    int64_t n_adj;
+    const uint64_t* adj;
+    const uint32_t* newly;
+    const uint32_t* offs;      // exclusive scan of newly
+    uint32_t* list;            // already offset to the first free entry
+    PSIM_HD void operator()(int64_t e) const
+    {
+        if (newly[e]) list[offs[e]] = (uint32_t)(adj[e] >> 32);
+    }
+};
+
+// element = touched slot index * 10 + cell selector.  Emits, for every touching pair
+// found, two entries (target slot << 32 | source slot).  A pair of two touched slots
+// is emitted by the one with the lower particle index.  count / scan / write.
+struct ConductionPairs {
+    int64_t n_moved;
+    GridView g;
+    const uint32_t* list;
+    const uint8_t* moved;
+    uint32_t* counts;
+    const uint32_t* offsets;
+    uint64_t* entries;
+    int32_t write_pass;
+    PSIM_HD void operator()(int64_t t) const
+    {
+        if (write_pass && counts[t] == 0) return;
+        int64_t m = t / 10;
+        int which = (int)(t - m * 10);
+        uint32_t x = list[m];
+        const CellBody bx = g.body[x];
+        uint32_t found = 0;
+        uint32_t at = write_pass ? offsets[t] : 0u;
+        for_each_slot_in_cell(g, x, which, [&](uint32_t y) {
+            const CellBody by = g.body[y];
+            double dx = by.x - bx.x, dy = by.y - bx.y;
+            double d2 = dx * dx + dy * dy;
+            double cd = (double)(bx.r + by.r);
+            if (!(d2 < cd * cd)) return;
+            if (moved[y] && by.idx < bx.idx) return;
+            if (write_pass) {
+                entries[at + found] = ((uint64_t)x << 32) | (uint64_t)y;
+                entries[at + found + 1] = ((uint64_t)y << 32) | (uint64_t)x;
+            }
+            found += 2;
+        });
+        if (!write_pass) counts[t] = found;
+    }
+};
+
+// entries sorted by target: the first entry of each target sums its sources in order
+// (particle_system.py:325-336 for the pair (p1, p2) = (lower index, higher index))
+struct ConductionApply {
+    int64_t n_entries;
+    const uint64_t* entries;
+    const CellBody* body;
+    const double* temp;        // index space, pre-conduction
+    const double* mass;
+    double heat_coeff;
+    double* delta;             // index space, zero elsewhere
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t t = (uint32_t)(entries[e] >> 32);
+        if (e > 0 && (uint32_t)(entries[e - 1] >> 32) == t) return;
+        uint32_t pt = body[t].idx;
+        double Tt = temp[pt], m = mass[pt], d = 0.0;
+        for (int64_t k = e; k < n_entries && (uint32_t)(entries[k] >> 32) == t; ++k) {
+            uint32_t ps = body[(uint32_t)entries[k]].idx;
+            double Ts = temp[ps];
+            if (pt < ps) {
+                double diff = Tt - Ts;
+                if (diff != 0) d -= (heat_coeff * diff) / m;
+            } else {
+                double diff = Ts - Tt;
+                if (diff != 0) d += (heat_coeff * diff) / m;
+            }
+        }
+        delta[pt] = d;
+    }
+};
+
 struct Cooling {
     int64_t n;
     double* temp;
@@ -1162,13 +1267,21 @@ struct WallsFlag {
     vec2* pos;
     vec2* vel;
     const int32_t* radii;
-    const double* temp;
+    double* temp;
     double W, H, explode_temp;
     int32_t do_walls, do_flag;
     uint8_t* boom;
     uint32_t* boom_count;
+    const double* delta;      // non-null: apply T = (T + delta) [* cool_factor] first (:498, :555-557)
+    double cool_factor;
+    int32_t do_cool;
     PSIM_HD void operator()(int64_t i) const
     {
+        if (delta) {
+            double T1 = temp[i] + delta[i];
+            if (do_cool) T1 = T1 * cool_factor;
+            temp[i] = T1;
+        }
         if (do_walls) {
             vec2 p = pos[i], v = vel[i];
             double r = (double)radii[i];

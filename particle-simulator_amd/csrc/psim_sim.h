@@ -103,7 +103,12 @@ public:
     // collisions
     size_t ccap = 0;
     DevBuf<uint64_t> h0[2], hc[2], hn[2], adj[2];
-    DevBuf<uint32_t> hsi, hsj, done, pcount, poffs;
+    DevBuf<uint32_t> hsi, hsj, done, pcount, poffs, moved_list;
+    DevBuf<uint8_t> moved;
+    DevBuf<double> cdelta;
+    DevBuf<uint64_t> cond_entries[2];
+    uint32_t n_moved = 0, n_coincident = 0;
+    bool moved_valid = false;      // moved / moved_list describe this step's collision stage
     DevBuf<int32_t> prevl;
     DevBuf<BodyState> outst;
     DevBuf<double> cvals, sum_pe, sum_ke, sum_heat, dseg;
@@ -366,10 +371,15 @@ public:
             cseg_ready = true;
         }
         if (ccap == 0) ensure_contact_capacity((size_t)n / 16 + 1024);
-        for (int it = 0; it < cfg.solver_iterations; ++it) collision_sweep();
+        moved.ensure((size_t)n);
+        moved_list.ensure((size_t)n);
+        be::dev_memset(st, moved.p, 0, (size_t)n);
+        n_moved = 0; n_coincident = 0;
+        for (int it = 0; it < cfg.solver_iterations; ++it) collision_sweep(it);
+        moved_valid = cfg.solver_iterations > 0;
     }
 
-    void collision_sweep()
+    void collision_sweep(int sweep)
     {
         GridView g = grid_view();
         const int slot_field_bits = ceil_log2_u64((uint64_t)n + 1);
@@ -384,15 +394,17 @@ public:
             ContactDetect d;
             d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
             d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? counters.p + 1 : nullptr;
+            d.coincident_counter = counters.p + 3;
             be::launch(st, n, d);
             be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)n, scan_tmp.p, counters.p);
             int64_t cwaves = (cells + 63) / 64;
             tmp32.ensure((size_t)cwaves);
             be::launch(st, cwaves * 64, WaveMaxOccupancy{cells, offsets.p, tmp32.p});
             be::launch(st, 64, FinalMax{cwaves, tmp32.p, counters.p + 2});
-            uint32_t three[3];
-            readback(three, counters.p, 12);
+            uint32_t three[4];
+            readback(three, counters.p, 16);
             n0 = three[0]; cand = three[1];
+            if (sweep == 0) n_coincident = three[3];
             slot_bits = ceil_log2_u64((uint64_t)three[2] + 1);
             if (slot_bits < 1) slot_bits = 1;
             g.slot_bits = slot_bits;
@@ -477,7 +489,7 @@ public:
                     // growing reallocates every contact buffer: restart the whole sweep
                     be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
                     ensure_contact_capacity(nNew);
-                    collision_sweep();
+                    collision_sweep(sweep);
                     return;
                 }
                 if (nNew > 0) {
@@ -525,13 +537,22 @@ public:
         cl.sum_pe = sum_pe.p; cl.sum_ke = sum_ke.p; cl.sum_heat = sum_heat.p;
         be::launch(st, nH, cl);
         be::reduce3_sum_f64(st, sum_pe.p, sum_ke.p, sum_heat.p, nH, red_tmp.p, red_out.p);
+        pcount.ensure(2 * (size_t)nH); poffs.ensure(2 * (size_t)nH);
         ContactFinalize f;
         f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outst.p; f.body = cbody.p;
-        f.pos = pos.p; f.vel = vel.p; f.temp = temp.p;
+        f.pos = pos.p; f.vel = vel.p; f.temp = temp.p; f.moved = moved.p; f.newly = pcount.p;
         be::launch(st, 2ll * nH, f);
+        be::exclusive_scan_u32(st, pcount.p, poffs.p, 2ull * nH, scan_tmp.p, counters.p + 5);
+        be::launch(st, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
         be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
         double t[3];
-        readback(t, red_out.p, 24);
+        be::copy_d2h(st, pinned, red_out.p, 24);
+        be::copy_d2h(st, (char*)pinned + 32, counters.p + 5, 4);
+        be::sync(st);
+        memcpy(t, pinned, 24);
+        uint32_t newly_moved;
+        memcpy(&newly_moved, (char*)pinned + 32, 4);
+        n_moved += newly_moved;
         coll_totals[0] += t[0]; coll_totals[1] += t[1]; coll_totals[2] += t[2];
         n_contacts += nH;
         if (cfg.debug) log_n += nH;
@@ -563,17 +584,67 @@ public:
     }
     void conduction_and_cooling() { conduction_and_cooling(0, n, nullptr); }
 
+    // The touching pairs all involve a slot the collision stage touched (see
+    // ConductionPairs): possible when that stage ran this step and met no pair at
+    // squared distance exactly zero.
+    bool sparse_conduction_possible() const
+    {
+        return (cfg.stage_mask & kStageConduction) && (cfg.stage_mask & kStageCollisions) && moved_valid &&
+               n_coincident == 0 && n > 0;
+    }
+
+    // Fills cdelta (index space) with the conduction temperature changes; the caller
+    // applies T = (T + delta) * cooling in its next streaming pass (walls_and_flags).
+    void conduction_sparse()
+    {
+        conduction_sparse_pairs();
+        if (cfg.debug) {
+            delta_dbg.ensure((size_t)n);
+            be::copy_d2d(st, delta_dbg.p, cdelta.p, (size_t)n * 8);
+        }
+    }
+    void conduction_sparse_pairs()
+    {
+        size_t c = (size_t)n;
+        GridView g = grid_view();
+        cdelta.ensure(c);
+        be::dev_memset(st, cdelta.p, 0, c * 8);
+        if (n_moved == 0) return;
+        int64_t nt = 10ll * n_moved;
+        pcount.ensure((size_t)nt); poffs.ensure((size_t)nt); scan_tmp.ensure(be::scan_temp_words((uint64_t)nt));
+        ConductionPairs k;
+        k.n_moved = n_moved; k.g = g; k.list = moved_list.p; k.moved = moved.p; k.counts = pcount.p; k.offsets = poffs.p;
+        k.entries = nullptr; k.write_pass = 0;
+        be::launch(st, nt, k);
+        be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)nt, scan_tmp.p, counters.p);
+        uint32_t ne = read_u32(counters.p);
+        if (ne == 0) return;
+        cond_entries[0].ensure(ne); cond_entries[1].ensure(ne);
+        sort_tmp.ensure(be::sort_temp_words(ne));
+        k.entries = cond_entries[0].p; k.write_pass = 1;
+        be::launch(st, nt, k);
+        uint64_t* ke[2] = {cond_entries[0].p, cond_entries[1].p};
+        int bits = 32 + ceil_log2_u64((uint64_t)n + 1);
+        // targets in ascending slot order; sources of one target in ascending slot order
+        int se = be::radix_sort_pairs<uint64_t>(st, ke, nullptr, ne, 0, bits, sort_tmp.p);
+        be::launch(st, ne, ConductionApply{(int64_t)ne, cond_entries[se].p, cbody.p, temp.p, mass.p, cfg.heat_coeff,
+                                           cdelta.p});
+    }
+
     // particle_system.py:500-516 and the explosion test of :658
-    uint32_t walls_and_flags()
+    uint32_t walls_and_flags(bool apply_delta = false)
     {
         bool w = (cfg.stage_mask & kStageWalls) != 0, f = (cfg.stage_mask & kStageExplosions) != 0;
-        if (n == 0 || (!w && !f)) return 0;
+        if (n == 0 || (!w && !f && !apply_delta)) return 0;
         boom.ensure((size_t)n);
         be::dev_memset(st, counters.p, 0, 4);
         WallsFlag k;
         k.n = n; k.pos = pos.p; k.vel = vel.p; k.radii = radii.p; k.temp = temp.p; k.W = cfg.bounds_w;
         k.H = cfg.bounds_h; k.explode_temp = cfg.explode_temp; k.do_walls = w; k.do_flag = f; k.boom = boom.p;
         k.boom_count = counters.p;
+        k.delta = apply_delta ? cdelta.p : nullptr;
+        k.cool_factor = 1.0 - cfg.damping;
+        k.do_cool = ((cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0) ? 1 : 0;
         be::launch(st, n, k);
         return f ? read_u32(counters.p) : 0;
     }
@@ -670,12 +741,14 @@ public:
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
         timer.mark(st, 5);
+        moved_valid = false;
         if (cfg.stage_mask & kStageCollisions) collisions();
         else { coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0; n_candidates = n_contacts = 0; log_n = 0; }
         timer.mark(st, 6);
-        conduction_and_cooling();
+        bool sparse = sparse_conduction_possible();
+        if (sparse) conduction_sparse(); else conduction_and_cooling();
         timer.mark(st, 7);
-        uint32_t nb = walls_and_flags();
+        uint32_t nb = walls_and_flags(sparse);
         if (nb > 0) explosions(nb);
         timer.mark(st, 8);
     }
@@ -708,23 +781,29 @@ public:
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
         timer.mark(st, 5);
+        moved_valid = false;
         if (cfg.stage_mask & kStageCollisions) collisions();
         else { coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0; n_candidates = n_contacts = 0; log_n = 0; }
         timer.mark(st, 6);
     }
+    // When conduction can run around the touched slots only it is cheap and every rank does
+    // all of it in stage_finish (this call then leaves temp_slots alone); otherwise the full
+    // sweep is split by slot range.  All ranks take the same branch: it depends on state only.
     void stage_conduction(int64_t lo, int64_t hi, double* temp_slots)
     {
         if (lo < 0 || hi > n || lo > hi) throw std::invalid_argument("psim: bad slot range");
-        conduction_and_cooling(lo, hi, temp_slots);
+        if (!sparse_conduction_possible()) conduction_and_cooling(lo, hi, temp_slots);
         timer.mark(st, 7);
     }
     void stage_finish(const double* temp_slots)
     {
         bool cond = (cfg.stage_mask & kStageConduction) != 0;
         bool cool = (cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0;
-        if (n > 0 && cond) be::launch(st, n, ScatterSlots{n, cbody.p, temp_slots, temp.p});
+        bool sparse = sparse_conduction_possible();
+        if (sparse) conduction_sparse();
+        else if (n > 0 && cond) be::launch(st, n, ScatterSlots{n, cbody.p, temp_slots, temp.p});
         else if (n > 0 && cool) be::launch(st, n, Cooling{n, temp.p, 1.0 - cfg.damping});
-        uint32_t nb = walls_and_flags();
+        uint32_t nb = walls_and_flags(sparse);
         if (nb > 0) explosions(nb);
         timer.mark(st, 8);
     }

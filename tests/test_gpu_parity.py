@@ -104,3 +104,12 @@ def test_near_coincident_knots_vs_oracle(clusters, per, spread):
     n, bounds = 3000, (1500, 900)
     st = parity.clustered_state(n, bounds, 77, clusters, per, spread)
     parity.run_against_oracle(n, SIM, 1, bounds, 3, HIP, state=st)
+
+
+@pytest.mark.parametrize("mask", [0, 2 | 4 | 8, 1 | 8, 31 - 2])
+def test_stage_masks_vs_oracle(mask):
+    """stage switches (the reference has none; the oracle mirrors them): gravity only;
+    conduction without collisions (full neighbour sweep instead of the sweep around
+    touched slots); collisions without conduction; everything but conduction"""
+    sim = dict(SIM, min_temp=0.2, max_temp=0.9)
+    parity.run_against_oracle(4000, sim, 9, (1100, 800), 3, HIP, stage_mask=mask)
