@@ -41,6 +41,24 @@ inline void copy_d2d(Stream st, void* d, const void* s, size_t bytes)
     if (bytes) PSIM_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, st));
 }
 inline void sync(Stream st) { PSIM_HIP(hipStreamSynchronize(st)); }
+// a second, non-blocking stream + events: memory-bound stages overlap the FP64-bound walk
+inline Stream stream_create()
+{
+    hipStream_t s = nullptr;
+    PSIM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+inline void stream_destroy(Stream s) { if (s) (void)hipStreamDestroy(s); }
+typedef hipEvent_t Event;
+inline Event event_create()
+{
+    hipEvent_t e = nullptr;
+    PSIM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return e;
+}
+inline void event_destroy(Event e) { if (e) (void)hipEventDestroy(e); }
+inline void event_record(Event e, Stream s) { PSIM_HIP(hipEventRecord(e, s)); }
+inline void stream_wait(Stream s, Event e) { PSIM_HIP(hipStreamWaitEvent(s, e, 0)); }
 // page-locked host memory: small device-to-host readbacks land here without a staging copy
 inline void* host_alloc_pinned(size_t bytes)
 {

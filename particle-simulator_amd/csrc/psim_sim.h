@@ -20,7 +20,7 @@ struct Config {
     int32_t stage_mask;
     int32_t walk_mode;      // 0: wave-cooperative walk, 1: one lane per particle
     int32_t debug;          // keep per-step debug arrays (contact log, delta temps)
-    int32_t reserved;
+    int32_t overlap;        // 1: grid build + first contact count pass on a side stream under the walk
 };
 
 template <class T>
@@ -127,6 +127,10 @@ public:
 
     // scratch
     DevBuf<uint32_t> sort_tmp, scan_tmp, counters;   // counters: 16 words
+    DevBuf<uint32_t> sort_tmp2, scan_tmp2, counters2;   // scratch of the side stream
+    be::Stream st2;
+    be::Event ev_drift, ev_side;
+    bool predetected = false;      // sweep 0's count pass already ran on the side stream
     DevBuf<double> red_tmp, red_out, terms[4];
 
     // per-step outputs
@@ -139,12 +143,23 @@ public:
     static constexpr size_t kPinnedBytes = 4096;
     void* pinned = nullptr;
 
-    ~Sim() { timer.destroy(); be::host_free_pinned(pinned); }
+    ~Sim()
+    {
+        timer.destroy();
+        be::host_free_pinned(pinned);
+        be::event_destroy(ev_drift);
+        be::event_destroy(ev_side);
+        be::stream_destroy(st2);
+    }
 
     explicit Sim(const Config& c) : cfg(c), st(0)
     {
         pinned = be::host_alloc_pinned(kPinnedBytes);
         counters.ensure(16);
+        counters2.ensure(16);
+        st2 = be::stream_create();
+        ev_drift = be::event_create();
+        ev_side = be::event_create();
         red_tmp.ensure(be::kReduceBlocks);
         red_out.ensure(8);
         depth_off.ensure(40);
@@ -254,21 +269,43 @@ public:
     }
 
     // particle_system.py:732-763
-    void build_grid()
+    void build_grid() { build_grid(st, sort_tmp); }
+    void build_grid(be::Stream s, DevBuf<uint32_t>& tmp)
     {
         size_t c = (size_t)n;
         uint64_t cells = (uint64_t)cfg.grid_w * (uint64_t)cfg.grid_h;
-        sort_tmp.ensure(be::sort_temp_words(c));
+        tmp.ensure(be::sort_temp_words(c));
         uint32_t* k[2] = {ckey[0].p, ckey[1].p};
         uint32_t* v[2] = {cperm[0].p, cperm[1].p};
         int bits = ceil_log2_u64(cells);
         if (bits < 1) bits = 1;
-        sorted_ckey = be::radix_sort_pairs<uint32_t>(st, k, v, (uint64_t)n, 0, bits, sort_tmp.p);
+        sorted_ckey = be::radix_sort_pairs<uint32_t>(s, k, v, (uint64_t)n, 0, bits, tmp.p);
         offsets.ensure(cells + 1);
-        be::launch(st, n + 1, SegmentOffsets{n, ckey[sorted_ckey].p, offsets.p, (uint32_t)cells});
+        be::launch(s, n + 1, SegmentOffsets{n, ckey[sorted_ckey].p, offsets.p, (uint32_t)cells});
         cbody.ensure(c);
-        be::launch(st, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pos.p, radii.p, cbody.p, cfg.grid_w});
+        be::launch(s, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pos.p, radii.p, cbody.p, cfg.grid_w});
         tree_n = n;
+    }
+
+    // count pass of the first collision sweep (positions do not change between the drift and
+    // the collision stage): per-slot contact counts, their scan, and the largest cell population
+    void detect_count(be::Stream s, DevBuf<uint32_t>& scan_scratch, uint32_t* ctr)
+    {
+        size_t c = (size_t)n;
+        const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
+        GridView g = grid_view();
+        pcount.ensure(c); poffs.ensure(c); scan_scratch.ensure(be::scan_temp_words(c));
+        be::dev_memset(s, ctr, 0, 64);
+        ContactDetect d;
+        d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
+        d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? ctr + 1 : nullptr;
+        d.coincident_counter = ctr + 3;
+        be::launch(s, n, d);
+        be::exclusive_scan_u32(s, pcount.p, poffs.p, (uint64_t)n, scan_scratch.p, ctr);
+        int64_t cwaves = (cells + 63) / 64;
+        tmp32.ensure((size_t)cwaves);
+        be::launch(s, cwaves * 64, WaveMaxOccupancy{cells, offsets.p, tmp32.p});
+        be::launch(s, 64, FinalMax{cwaves, tmp32.p, ctr + 2});
     }
 
     // quadtree.py:177-196 (build) as sort + links + emit + bottom-up COM
@@ -388,21 +425,17 @@ public:
         int key_bits = 64;
         const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
         {
-            size_t c = (size_t)n;
-            pcount.ensure(c); poffs.ensure(c); scan_tmp.ensure(be::scan_temp_words(c));
-            be::dev_memset(st, counters.p, 0, 64);
+            const uint32_t* ctr = counters.p;
+            if (sweep == 0 && predetected) {
+                ctr = counters2.p;          // already computed on the side stream (joined by the caller)
+                predetected = false;
+            } else {
+                detect_count(st, scan_tmp, counters.p);
+            }
             ContactDetect d;
-            d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
-            d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? counters.p + 1 : nullptr;
-            d.coincident_counter = counters.p + 3;
-            be::launch(st, n, d);
-            be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)n, scan_tmp.p, counters.p);
-            int64_t cwaves = (cells + 63) / 64;
-            tmp32.ensure((size_t)cwaves);
-            be::launch(st, cwaves * 64, WaveMaxOccupancy{cells, offsets.p, tmp32.p});
-            be::launch(st, 64, FinalMax{cwaves, tmp32.p, counters.p + 2});
+            d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.coincident_counter = nullptr;
             uint32_t three[4];
-            readback(three, counters.p, 16);
+            readback(three, ctr, 16);
             n0 = three[0]; cand = three[1];
             if (sweep == 0) n_coincident = three[3];
             slot_bits = ceil_log2_u64((uint64_t)three[2] + 1);
@@ -732,14 +765,28 @@ public:
         timer.mark(st, 0);
         keys_and_drift(true);
         timer.mark(st, 1);
-        build_grid();
+        // The grid build and the first contact sweep's count pass are memory-bound and depend
+        // only on the drifted positions: they run on a side stream underneath the tree build
+        // and the FP64-bound walk, and are joined before the collision stage.
+        const bool side = cfg.overlap != 0 && n > 0;
+        if (!side) build_grid();
         timer.mark(st, 2);
         build_tree();
         timer.mark(st, 3);
+        if (side) {
+            // released when the tree is built, so that it shares the device with the walk (FP64-bound)
+            // and not with the tree build (memory-bound like itself)
+            be::event_record(ev_drift, st);
+            be::stream_wait(st2, ev_drift);
+            build_grid(st2, sort_tmp2);
+            if (cfg.stage_mask & kStageCollisions) { detect_count(st2, scan_tmp2, counters2.p); predetected = true; }
+            be::event_record(ev_side, st2);
+        }
         gravity(acc2.p);
         timer.mark(st, 4);
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
+        if (side) be::stream_wait(st, ev_side);
         timer.mark(st, 5);
         moved_valid = false;
         if (cfg.stage_mask & kStageCollisions) collisions();

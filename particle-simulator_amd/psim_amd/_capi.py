@@ -40,7 +40,7 @@ class PsimConfig(ctypes.Structure):
         ("explode_temp", ctypes.c_double),
         ("cell_size", ctypes.c_int32), ("grid_w", ctypes.c_int32), ("grid_h", ctypes.c_int32),
         ("solver_iterations", ctypes.c_int32), ("stage_mask", ctypes.c_int32),
-        ("walk_mode", ctypes.c_int32), ("debug", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("walk_mode", ctypes.c_int32), ("debug", ctypes.c_int32), ("overlap", ctypes.c_int32),
     ]
 
 

@@ -32,7 +32,7 @@ def grid_geometry(config, bounds):
     return cell_size, int(np.ceil(b[0] / cell_size)), int(np.ceil(b[1] / cell_size))
 
 
-def make_config(config, bounds, stage_mask=_capi.STAGE_ALL, walk_mode=0, debug=False):
+def make_config(config, bounds, stage_mask=_capi.STAGE_ALL, walk_mode=0, debug=False, overlap=True):
     """dict from config.json's "simulation" section -> struct psim_config.
     Required and optional keys and their defaults follow particle_system.py:359-361,
     383, 397, 430-431, 462, 555, 673."""
@@ -53,6 +53,7 @@ def make_config(config, bounds, stage_mask=_capi.STAGE_ALL, walk_mode=0, debug=F
     c.stage_mask = int(stage_mask)
     c.walk_mode = int(walk_mode)
     c.debug = 1 if debug else 0
+    c.overlap = 1 if overlap else 0
     return c
 
 
@@ -63,7 +64,7 @@ _FIELDS = ("positions", "velocities", "accelerations", "masses", "inverse_masses
 class ParticleSystem:
     def __init__(self, num_particles: int, config: dict, rng: np.random.Generator, bounds: tuple,
                  *, device: int = 0, stage_mask: int = _capi.STAGE_ALL, walk_mode: int = 0,
-                 debug: bool = False, state: dict = None, library: str = None):
+                 debug: bool = False, state: dict = None, library: str = None, overlap: bool = True):
         """Positional arguments as particle_system.py:355.  Keyword-only extras:
         device ordinal, stage mask (benchmarks), tree-walk variant, debug arrays,
         an explicit initial `state` dict (positions, masses, temperatures[,
@@ -81,6 +82,7 @@ class ParticleSystem:
         self.ke_loss_collisions = 0.0
         self.heat_generated_collisions = 0.0
         self._stage_mask, self._walk_mode, self._debug = stage_mask, walk_mode, debug
+        self._overlap = overlap
         self._device = device
         n = self.num_particles
 
@@ -100,7 +102,7 @@ class ParticleSystem:
         radii = np.sqrt(masses).astype(int)                 # particle_system.py:376 (int64)
 
         self.cell_size, self.grid_width, self.grid_height = grid_geometry(config, bounds)
-        self._cfg = make_config(config, bounds, stage_mask, walk_mode, debug)
+        self._cfg = make_config(config, bounds, stage_mask, walk_mode, debug, overlap)
         self._cfg_key = self._config_key()
         self._ctx = ctypes.c_void_p()
         _capi.check(self._lib, self._lib.psim_create(ctypes.byref(self._cfg), device, ctypes.byref(self._ctx)))
@@ -126,7 +128,7 @@ class ParticleSystem:
         step (particle_system.py:430,462,555,673): push it when it changed."""
         key = self._config_key()
         if key != self._cfg_key:
-            self._cfg = make_config(self.config, self.bounds, self._stage_mask, self._walk_mode, self._debug)
+            self._cfg = make_config(self.config, self.bounds, self._stage_mask, self._walk_mode, self._debug, self._overlap)
             _capi.check(self._lib, self._lib.psim_set_config(self._ctx, ctypes.byref(self._cfg)))
             self._cfg_key = key
 

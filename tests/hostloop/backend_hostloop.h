@@ -26,6 +26,13 @@ inline void copy_h2d(Stream, void* d, const void* h, size_t bytes) { if (bytes) 
 inline void copy_d2h(Stream, void* h, const void* d, size_t bytes) { if (bytes) memcpy(h, d, bytes); }
 inline void copy_d2d(Stream, void* d, const void* s, size_t bytes) { if (bytes) memmove(d, s, bytes); }
 inline void sync(Stream) {}
+inline Stream stream_create() { return 1; }
+inline void stream_destroy(Stream) {}
+typedef int Event;
+inline Event event_create() { return 0; }
+inline void event_destroy(Event) {}
+inline void event_record(Event, Stream) {}
+inline void stream_wait(Stream, Event) {}
 inline void* host_alloc_pinned(size_t bytes) { return calloc(bytes ? bytes : 16, 1); }
 inline void host_free_pinned(void* p) { free(p); }
 
