@@ -497,14 +497,6 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
         if (COUNT) {
             const unsigned long long take_mask = __builtin_amdgcn_ballot_w64(take);
             visits += active ? 1u : 0u; inter += take ? 1u : 0u; trips += 1u; force_trips += take_mask ? 1u : 0u;
-            const int pc = __popcll(take_mask);
-            const int pa = __popcll(__builtin_amdgcn_ballot_w64(active));
-            if ((threadIdx.x & 63) == 0) {
-                int b = pc == 0 ? 0 : pc <= 8 ? 1 : pc <= 16 ? 2 : pc <= 32 ? 3 : pc < 64 ? 4 : 5;
-                int ba = pa == 0 ? 0 : pa <= 8 ? 1 : pa <= 16 ? 2 : pa <= 32 ? 3 : pa < 64 ? 4 : 5;
-                atomicAdd(&counters[4 + (leaf ? 6 : 0) + b], 1ull);
-                atomicAdd(&counters[16 + (leaf ? 6 : 0) + ba], 1ull);
-            }
         }
         if (take) {                                          // skipped as a whole when no lane accepts
             double ri = rsqrt_refined(d2 + softening);

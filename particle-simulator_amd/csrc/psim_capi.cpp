@@ -279,13 +279,6 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     unsigned long long h[32];
     psim::be::copy_d2h(s->st, h, cnt.p, 256);
     psim::be::sync(s->st);
-    if (getenv("PSIM_WALK_HIST")) {
-        const char* names[4] = {"take/internal", "take/leaf", "active/internal", "active/leaf"};
-        for (int g = 0; g < 4; ++g) {
-            fprintf(stderr, "walk hist %-16s lanes 0:%llu 1-8:%llu 9-16:%llu 17-32:%llu 33-63:%llu 64:%llu\n", names[g],
-                    h[4 + 6 * g], h[5 + 6 * g], h[6 + 6 * g], h[7 + 6 * g], h[8 + 6 * g], h[9 + 6 * g]);
-        }
-    }
     out[0] = (int64_t)h[0];
     out[1] = (int64_t)h[1];
     out[2] = (int64_t)h[2];
