@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--walk-mode", type=int, default=0)
+    ap.add_argument("--brute", type=int, default=0,
+                    help="also time the all-pairs cross-check kernel on this many particles")
     args = ap.parse_args()
 
     import torch
@@ -189,6 +191,17 @@ def main():
                           "solver_rounds": counts["solver_rounds"], "tree_nodes": counts["tree_nodes"],
                           "particles": counts["particles"]},
         }
+        if args.brute:
+            nb = args.brute
+            side = float(np.sqrt(nb / 1e-3))
+            bs = ParticleSystem(nb, dict(SIM), np.random.default_rng(7), (side, side), device=local_rank)
+            bs.brute_force_accelerations()
+            ms = min(bs.brute_force_accelerations()[1] for _ in range(3))
+            tf = 20.0 * nb * (nb - 1) / (ms * 1e-3) / 1e12
+            out["brute_force"] = {"kernel": "brute_force_kernel", "particles": nb, "kernel_ms": ms, "bound": "valu",
+                                  "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": tf / PEAK_FP64_VALU_TFLOPS}
+            bs.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -145,6 +145,12 @@ int64_t psim_explosion_events(psim_context* ctx, psim_explosion_event* buf, int6
  * summed over 64-lane waves, [3] trips in which some lane accepted */
 int psim_walk_counts(psim_context* ctx, int64_t out[4]);
 
+/* cross-check (no counterpart in the reference): all-pairs softened gravity of the
+ * current state with the force law of particle_system.py:86-93, O(n^2) FP64.
+ * accelerations_out: host (n,2) float64.  kernel_ms (may be NULL) receives the
+ * device time of the kernel; it performs 20 n (n-1) flops by the walk's accounting. */
+int psim_brute_force_gravity(psim_context* ctx, double* accelerations_out, double* kernel_ms);
+
 /* parity hooks: copy a named internal device array to the host.
  * psim_debug_size returns the element count (or < 0 for an unknown name);
  * psim_debug_fetch copies min(bytes, size) bytes.  Names: key perm L owned base

@@ -566,3 +566,42 @@ struct StageTimer {
 };
 }  // namespace be
 }  // namespace psim
+
+// ------------------------------------------------------------------ brute-force cross-check
+// All-pairs softened gravity, a_i = G sum_j m_j (x_j - x_i) (d^2 + s)^-1.5 over d^2 > 0
+// (the force law of particle_system.py:86-93 applied to every particle instead of
+// tree nodes).  256 targets per workgroup, one per lane; sources staged through LDS
+// in tiles of 256 and read back as wave-wide broadcasts.  FP64 VALU-bound: used to
+// validate the tree walk (theta = 0 must reproduce it) and as a roofline yardstick.
+namespace psim {
+namespace be {
+__global__ void __launch_bounds__(256) brute_force_kernel(int64_t n, const vec2* __restrict__ pos,
+                                                          const double* __restrict__ mass,
+                                                          vec2* __restrict__ acc_out, double g_const, double softening)
+{
+    __shared__ double sx[256], sy[256], sm[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double px = 0.0, py = 0.0;
+    if (i < n) { vec2 p = pos[i]; px = p.x; py = p.y; }
+    double ax = 0.0, ay = 0.0;
+    for (int64_t base = 0; base < n; base += 256) {
+        int64_t j = base + threadIdx.x;
+        if (j < n) { vec2 q = pos[j]; sx[threadIdx.x] = q.x; sy[threadIdx.x] = q.y; sm[threadIdx.x] = mass[j]; }
+        else { sx[threadIdx.x] = px; sy[threadIdx.x] = py; sm[threadIdx.x] = 0.0; }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 256; ++k) {
+            double dx = sx[k] - px, dy = sy[k] - py;
+            double d2 = fma(dx, dx, dy * dy);
+            double ri = rsqrt_refined(d2 + softening);
+            double f = (sm[k] * ri) * (ri * ri);
+            f = d2 > 0.0 ? f : 0.0;
+            ax = fma(f, dx, ax);
+            ay = fma(f, dy, ay);
+        }
+        __syncthreads();
+    }
+    if (i < n) { vec2 a; a.x = g_const * ax; a.y = g_const * ay; acc_out[i] = a; }
+}
+}  // namespace be
+}  // namespace psim

@@ -303,6 +303,55 @@ int psim_walk_counts(psim_context* ctx, int64_t out[4])
     PSIM_TRY(ctx && out, walk_counts_impl(ctx, out))
 }
 
+static void brute_force_impl(psim_context* ctx, double* out, double* kernel_ms)
+{
+    use_device(ctx->device);
+    psim::Sim* s = ctx->sim;
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (s->n == 0) return;
+    psim::DevBuf<psim::vec2> acc;
+    acc.ensure((size_t)s->n);
+#if !defined(PSIM_HOSTLOOP)
+    hipEvent_t e0, e1;
+    PSIM_HIP(hipEventCreate(&e0));
+    PSIM_HIP(hipEventCreate(&e1));
+    PSIM_HIP(hipEventRecord(e0, s->st));
+    hipLaunchKernelGGL(psim::be::brute_force_kernel, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, s->st, s->n,
+                       (const psim::vec2*)s->pos.p, (const double*)s->mass.p, acc.p, s->cfg.gravity_constant,
+                       s->cfg.softening);
+    PSIM_HIP(hipGetLastError());
+    PSIM_HIP(hipEventRecord(e1, s->st));
+    PSIM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PSIM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (kernel_ms) *kernel_ms = (double)ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+#else
+    for (int64_t i = 0; i < s->n; ++i) {
+        double ax = 0.0, ay = 0.0;
+        for (int64_t j = 0; j < s->n; ++j) {
+            double dx = s->pos.p[j].x - s->pos.p[i].x, dy = s->pos.p[j].y - s->pos.p[i].y;
+            double d2 = dx * dx + dy * dy;
+            if (d2 > 0) {
+                double f = s->mass.p[j] * psim::inv_cube_soft(d2 + s->cfg.softening);
+                ax += f * dx;
+                ay += f * dy;
+            }
+        }
+        acc.p[i].x = s->cfg.gravity_constant * ax;
+        acc.p[i].y = s->cfg.gravity_constant * ay;
+    }
+#endif
+    psim::be::copy_d2h(s->st, out, acc.p, (size_t)s->n * 16);
+    psim::be::sync(s->st);
+}
+
+int psim_brute_force_gravity(psim_context* ctx, double* accelerations_out, double* kernel_ms)
+{
+    PSIM_TRY(ctx && accelerations_out, brute_force_impl(ctx, accelerations_out, kernel_ms))
+}
+
 int psim_stage_times(psim_context* ctx, double out_ms[8])
 {
     PSIM_TRY(ctx && out_ms, {

@@ -250,6 +250,15 @@ class ParticleSystem:
         self.last_walk_trips = (int(out[2]), int(out[3]))
         return int(out[0]), int(out[1])
 
+    def brute_force_accelerations(self):
+        """All-pairs softened gravity of the current state (O(n^2) cross-check).
+        Returns (accelerations (n,2), kernel milliseconds)."""
+        out = np.empty((self.num_particles, 2))
+        ms = ctypes.c_double(0.0)
+        _capi.check(self._lib, self._lib.psim_brute_force_gravity(
+            self._ctx, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms)))
+        return out, ms.value
+
     def stage_times_ms(self):
         out = (ctypes.c_double * 8)()
         _capi.check(self._lib, self._lib.psim_stage_times(self._ctx, out))

@@ -113,3 +113,17 @@ def test_stage_masks_vs_oracle(mask):
     touched slots); collisions without conduction; everything but conduction"""
     sim = dict(SIM, min_temp=0.2, max_temp=0.9)
     parity.run_against_oracle(4000, sim, 9, (1100, 800), 3, HIP, stage_mask=mask)
+
+
+def test_tree_walk_against_all_pairs():
+    """theta = 0 opens every node: the walk must reproduce the all-pairs FP64 sum up
+    to summation order; theta = 0.5 stays within Barnes-Hut's approximation error"""
+    from psim_amd.particle_system import ParticleSystem
+    n, bounds = 20000, (3000, 2000)
+    for theta, tol in ((0.0, 1e-11), (0.5, 5e-2)):
+        s = ParticleSystem(n, dict(SIM, barnes_hut_theta=theta), np.random.default_rng(4), bounds)
+        s._calculate_gravity()
+        brute, ms = s.brute_force_accelerations()
+        scale = np.abs(brute).max()
+        assert np.abs(s.accelerations - brute).max() <= tol * scale, theta
+        assert ms > 0

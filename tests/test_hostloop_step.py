@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import parity
+from psim_amd.particle_system import ParticleSystem
 
 HOSTLOOP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostloop")
 HOSTLOOP = os.path.join(HOSTLOOP_DIR, "libpsim_hostloop.so")
@@ -62,3 +63,16 @@ def test_stage_masks_vs_oracle(mask):
     touched slots); collisions without conduction; everything but conduction"""
     sim = dict(SIM, min_temp=0.2, max_temp=0.9)
     parity.run_against_oracle(4000, sim, 9, (1100, 800), 3, HOSTLOOP, walk_mode=1, stage_mask=mask)
+
+
+def test_tree_walk_against_all_pairs():
+    """theta = 0 opens every node, so the walk must reproduce the all-pairs sum (to
+    summation order); theta = 0.5 must stay within Barnes-Hut's approximation error"""
+    n, bounds = 1500, (700, 500)
+    for theta, tol in ((0.0, 1e-11), (0.5, 5e-2)):
+        s = ParticleSystem(n, dict(SIM, barnes_hut_theta=theta), np.random.default_rng(4), bounds,
+                           library=HOSTLOOP, walk_mode=1)
+        s._calculate_gravity()
+        brute, _ = s.brute_force_accelerations()
+        scale = np.abs(brute).max()
+        assert np.abs(s.accelerations - brute).max() <= tol * scale, theta
