@@ -29,8 +29,8 @@ def build(force=False):
     if (not force and os.path.exists(_SO)
             and os.path.getmtime(_SO) >= os.path.getmtime(_SRC)):
         return _SO
-    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-shared",
-                           "-fPIC", "-o", _SO, _SRC, "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                           "-shared", "-fPIC", "-o", _SO, _SRC, "-lm"])
     return _SO
 
 
@@ -66,6 +66,7 @@ def lib():
         L.orc_update.restype = ctypes.c_int
         L.orc_enable_contact_log.argtypes = [ctypes.c_void_p, ctypes.c_int64]
         L.orc_set_fast_pow.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -200,6 +201,10 @@ class OracleSystem:
 
     def set_fast_pow(self, on):
         lib().orc_set_fast_pow(self._h, 1 if on else 0)
+
+    def set_threads(self, k):
+        """threads of the per-particle gravity loop (results do not depend on it)"""
+        lib().orc_set_threads(self._h, int(k))
 
     def build_grid(self):
         lib().orc_build_grid(self._h)

@@ -17,8 +17,14 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this file.  The product library never does.
  *
- * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC
  *        (contraction off: the reference's strict stages must not fuse a*b+c).
+ *
+ * Threads: everything is sequential, as in the reference, except that
+ * orc_set_threads(k > 1) lets the per-particle gravity loop (independent
+ * iterations, each writing only its own acceleration) run on k threads so the
+ * tests can afford full-size clouds.  Results do not depend on k.  The
+ * benchmark's CPU baseline runs with k = 1.
  */
 #include <math.h>
 #include <stdint.h>
@@ -67,6 +73,7 @@ typedef struct {
     int32_t *exploded;             /* indices removed by the last step */
     int64_t n_exploded;
     int fast_pow;                  /* 0: libm pow as CPython; 1: rsqrt form (timing) */
+    int threads;                   /* gravity loop threads (tests only), default 1 */
 } orc_system;
 
 /* ---------------------------------------------------------------- grid */
@@ -290,6 +297,8 @@ static void gravity(orc_system *s, int64_t *visits, int64_t *inter)
     memset(s->acc, 0, sizeof(double) * 2 * s->n);
     s->tree_cached = 1;
     if (s->num_nodes == 0) return;
+    int threads = s->threads > 1 ? s->threads : 1;
+    #pragma omp parallel for reduction(+:v, it) num_threads(threads) schedule(static, 4096) if (threads > 1)
     for (int64_t i = 0; i < s->n; i++) {
         double fx, fy;
         traverse(s, i, 0, &fx, &fy, &v, &it);
@@ -612,6 +621,7 @@ void orc_destroy(orc_system *s)
 }
 
 void orc_set_fast_pow(orc_system *s, int on) { s->fast_pow = on; }
+void orc_set_threads(orc_system *s, int k) { s->threads = k; }
 
 void orc_enable_contact_log(orc_system *s, int64_t cap)
 {

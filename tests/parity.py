@@ -93,11 +93,16 @@ def run_golden_stepwise(name, library, walk_mode=0):
 
 
 def run_against_oracle(n, sim, seed, bounds, steps, library, walk_mode=0, state=None, stage_mask=31,
-                       check_contacts=True):
-    """Same seeded inputs through this build and through the C oracle."""
+                       check_contacts=True, oracle_threads=1, oracle_fast_pow=False):
+    """Same seeded inputs through this build and through the C oracle.
+    oracle_threads / oracle_fast_pow only make the oracle's gravity loop affordable at
+    full benchmark sizes (threads do not change its results; the rsqrt form of x**-1.5
+    changes them by a few ulp, far inside the tolerances below)."""
     from oracle.oracle import OracleSystem
     rng_a, rng_b = np.random.default_rng(seed), np.random.default_rng(seed)
     o = OracleSystem(n, sim, rng_a, bounds, state=state, stage_mask=stage_mask)
+    o.set_threads(oracle_threads)
+    o.set_fast_pow(oracle_fast_pow)
     s = ParticleSystem(n, dict(sim), rng_b, bounds, library=library, walk_mode=walk_mode, debug=True,
                        state=state, stage_mask=stage_mask)
     o.enable_contact_log(1 << 22)

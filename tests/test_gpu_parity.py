@@ -67,6 +67,28 @@ def test_oracle_50k_full_physics():
     parity.run_against_oracle(50000, SIM, 5, (10000, 5000), 3, HIP)
 
 
+def _host_threads():
+    import os
+    return max(1, min(16, os.cpu_count() or 1))
+
+
+def test_full_size_4Mi_all_stages_vs_oracle():
+    """the benchmark's single-GPU configuration itself (4,194,304 particles, bounds
+    90000x45000, seed 42, every stage): prime + one full step against the oracle --
+    node count, grid, contact pair list (about 250k contacts), exploded set bit-exact,
+    state within tolerance"""
+    parity.run_against_oracle(1 << 22, SIM, 42, (90000, 45000), 1, HIP,
+                              oracle_threads=_host_threads(), oracle_fast_pow=True)
+
+
+def test_full_size_1Mi_disk_gravity_only_vs_oracle():
+    """the 1Mi uniform-disk gravity-only configuration, two steps"""
+    import bench
+    label, n, bounds, state, mask = bench.workload("c1")
+    parity.run_against_oracle(n, SIM, 42, bounds, 2, HIP, state=state, stage_mask=mask,
+                              oracle_threads=_host_threads(), oracle_fast_pow=True)
+
+
 def test_oracle_dense_hot_20k():
     """4x default density, hot start: contact chains and explosions"""
     sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)
