@@ -3,6 +3,7 @@
 // sort, exclusive scan, ordered f64 reduction.  64-lane wavefronts throughout.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdexcept>
 #include <string>
 #include <stdint.h>
@@ -226,56 +227,61 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
 }
 
 // ------------------------------------------------------------------ radix sort (LSD, 8-bit digits)
-// Per pass: (1) per-tile digit histogram, (2) exclusive scan of the
-// digit-major [256][tiles] table, (3) scatter: each 256-lane workgroup ranks its
-// 2048-key tile stably (wave-level digit matching by ballot + per-wave LDS
-// counters), stages the tile in LDS in sorted order and writes runs of equal
-// digit to their global offsets, so stores are contiguous per digit run.
+// One launch per digit pass ("one sweep"): a first kernel counts, for every pass at
+// once, how many keys carry each digit value (the counts do not depend on the order
+// the earlier passes leave).  A pass kernel's 256-lane workgroup then takes the next
+// 2048-key tile (tile numbers are handed out by an atomic counter, so every tile a
+// workgroup can wait for has already started), ranks it stably (wave-level digit
+// matching by ballot + per-wave LDS counters), publishes its per-digit counts and
+// finds its global offsets by looking back over the tiles before it: a predecessor
+// shows either its own count (keep looking) or the running total up to and including
+// itself (stop).  The tile is reordered in LDS so the stores are contiguous per
+// digit run.  Sorts of at most one tile run every pass inside one workgroup.
 constexpr int kSortItems = 8;
 constexpr int kSortTile = 256 * kSortItems;
+constexpr int kMaxSortPasses = 8;
+constexpr uint32_t kLookValue = 0x3fffffffu;
+constexpr uint32_t kLookLocal = 1u << 30;       // this tile's own count
+constexpr uint32_t kLookInclusive = 2u << 30;   // count of this tile and every tile before it
+constexpr uint32_t kLookSpinLimit = 1u << 26;   // polls before a waiting lane gives up (seconds)
 
-template <class KeyT>
-__global__ void __launch_bounds__(256) sort_hist_kernel(const KeyT* keys, uint32_t n, int shift, uint32_t ntiles,
-                                                        uint32_t* tile_hist)
+// word set by a pass kernel whose look-back gave up; one per device, read by the host
+// once per step.  A tile that gives up writes nothing, so a failed sort stays in bounds.
+inline uint32_t* sort_fault_word()
 {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t base = blockIdx.x * kSortTile;
-#pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        uint32_t idx = base + k * 256 + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+    static uint32_t* words[64] = {};
+    int dev = 0;
+    PSIM_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) throw std::runtime_error("sort_fault_word: device index out of range");
+    if (!words[dev]) {
+        words[dev] = (uint32_t*)dev_alloc(64);
+        PSIM_HIP(hipMemset(words[dev], 0, 64));
     }
-    __syncthreads();
-    tile_hist[threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    return words[dev];
 }
 
+struct SortShared {
+    uint32_t cnt[4][256];
+    uint32_t dstart[256];
+    uint32_t wsum[8];
+};
+
+// Stable rank of the tile's items by digit.  On return rank[k] is item k's position
+// among its wave's items of the same digit, s.cnt[w][d] the number of such items in
+// the waves before w, s.dstart[d] where digit d starts in the tile; the return value
+// is the tile's count of digit threadIdx.x.
 template <class KeyT>
-__global__ void __launch_bounds__(256) sort_scatter_kernel(const KeyT* kin, const uint32_t* vin, KeyT* kout,
-                                                           uint32_t* vout, uint32_t n, int shift,
-                                                           uint32_t ntiles, const uint32_t* gbase)
+__device__ __forceinline__ uint32_t tile_rank(SortShared& s, const KeyT (&key)[kSortItems], uint32_t tile_n, int shift,
+                                              uint32_t (&rank)[kSortItems])
 {
-    __shared__ uint32_t cnt[4][256];
-    __shared__ uint32_t dstart[256];
-    __shared__ uint32_t wsum[8];
-    __shared__ KeyT skey[kSortTile];
-    __shared__ uint32_t sval[kSortTile];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < 4 * 256; i += 256) (&cnt[0][0])[i] = 0;
+    for (int i = tid; i < 4 * 256; i += 256) (&s.cnt[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t tile_base = blockIdx.x * kSortTile;
-    const uint32_t tile_n = (n - tile_base < (uint32_t)kSortTile) ? (n - tile_base) : (uint32_t)kSortTile;
-    KeyT key[kSortItems];
-    uint32_t val[kSortItems];
-    uint32_t rank[kSortItems];
     const uint64_t lane_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
         bool valid = off < tile_n;
-        key[k] = valid ? kin[tile_base + off] : (KeyT)0;
-        val[k] = (valid && vin) ? vin[tile_base + off] : 0u;
         uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -289,8 +295,8 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const KeyT* kin, cons
         int leader = __ffsll((long long)peers) - 1;
         uint32_t old = 0;
         if (valid && lane == leader) {
-            old = cnt[w][d];
-            cnt[w][d] = old + (uint32_t)__popcll(peers);
+            old = s.cnt[w][d];
+            s.cnt[w][d] = old + (uint32_t)__popcll(peers);
         }
         old = __shfl(old, leader, 64);
         rank[k] = old + r;
@@ -299,31 +305,174 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const KeyT* kin, cons
     // per digit: exclusive prefix over the 4 waves, then over digits
     uint32_t run = 0;
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) { uint32_t c = cnt[ww][tid]; cnt[ww][tid] = run; run += c; }
+    for (int ww = 0; ww < 4; ++ww) { uint32_t c = s.cnt[ww][tid]; s.cnt[ww][tid] = run; run += c; }
     uint32_t total;
-    uint32_t ds = block_exclusive_scan(run, wsum, &total);
-    dstart[tid] = ds;
+    uint32_t ds = block_exclusive_scan(run, s.wsum, &total);
+    s.dstart[tid] = ds;
     __syncthreads();
+    return run;
+}
+
+template <class KeyT>
+__global__ void __launch_bounds__(256) sort_digit_counts_kernel(const KeyT* keys, uint32_t n, int bit_lo, int passes,
+                                                                uint32_t items_per_block, uint32_t* digit_counts)
+{
+    __shared__ uint32_t h[kMaxSortPasses][256];
+    for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t lo = (uint64_t)blockIdx.x * items_per_block;
+    uint64_t hi = lo + items_per_block;
+    if (hi > n) hi = n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        KeyT k = keys[i];
+        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(uint32_t)(k >> (bit_lo + 8 * p)) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; ++p) {
+        uint32_t c = h[p][threadIdx.x];
+        if (c) atomicAdd(&digit_counts[p * 256 + threadIdx.x], c);
+    }
+}
+
+template <class KeyT>
+__global__ void __launch_bounds__(256) sort_pass_kernel(const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout,
+                                                        uint32_t n, int shift, const uint32_t* digit_counts,
+                                                        uint32_t* status, uint32_t* next_tile, uint32_t* fault)
+{
+    __shared__ SortShared s;
+    __shared__ KeyT skey[kSortTile];
+    __shared__ uint32_t sval[kSortTile];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t s_tile, s_failed;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (tid == 0) { s_tile = atomicAdd(next_tile, 1u); s_failed = 0; }
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t tile_base = tile * kSortTile;
+    if (tile_base >= n) return;            // cannot happen: the grid has exactly ceil(n / tile) workgroups
+    const uint32_t tile_n = (n - tile_base < (uint32_t)kSortTile) ? (n - tile_base) : (uint32_t)kSortTile;
+    KeyT key[kSortItems];
+    uint32_t val[kSortItems];
+    uint32_t rank[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
+        bool valid = off < tile_n;
+        key[k] = valid ? kin[tile_base + off] : (KeyT)0;
+        val[k] = (valid && vin) ? vin[tile_base + off] : 0u;
+    }
+    const uint32_t mine = tile_rank<KeyT>(s, key, tile_n, shift, rank);
+    // publish this tile's count of digit `tid`, then look back
+    uint32_t* my_status = status + (size_t)tile * 256 + tid;
+    __hip_atomic_store(my_status, (tile == 0 ? kLookInclusive : kLookLocal) | mine, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t before = 0;
+    if (tile > 0) {
+        bool ok = true;
+        int64_t t = (int64_t)tile - 1;
+        uint32_t polls = 0;
+        while (t >= 0) {
+            uint32_t v = __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t f = v >> 30;
+            if (f == 0) {
+                if ((++polls & 255u) == 0 &&
+                    (polls >= kLookSpinLimit ||
+                     __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            before += v & kLookValue;
+            if (f == 2) break;
+            --t;
+        }
+        if (ok) {
+            __hip_atomic_store(my_status, kLookInclusive | ((before + mine) & kLookValue), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_failed = 1;
+        }
+    }
+    // digits below `tid` over the whole input
+    uint32_t total;
+    uint32_t below = block_exclusive_scan(digit_counts[tid], s.wsum, &total);
+    gbase[tid] = below + before;
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
         if (off < tile_n) {
             uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
-            uint32_t lp = dstart[d] + cnt[w][d] + rank[k];
+            uint32_t lp = s.dstart[d] + s.cnt[w][d] + rank[k];
             skey[lp] = key[k];
             sval[lp] = val[k];
         }
     }
     __syncthreads();
+    if (s_failed) return;
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         uint32_t pos = (uint32_t)(k * 256 + tid);
         if (pos < tile_n) {
             KeyT kk = skey[pos];
             uint32_t d = (uint32_t)(kk >> shift) & 255u;
-            uint32_t g = gbase[d * ntiles + blockIdx.x] + (pos - dstart[d]);
-            kout[g] = kk;
-            if (vout) vout[g] = sval[pos];
+            uint32_t g = gbase[d] + (pos - s.dstart[d]);
+            if (g < n) {
+                kout[g] = kk;
+                if (vout) vout[g] = sval[pos];
+            }
+        }
+    }
+}
+
+// n <= one tile: every pass in one workgroup, keys staged through LDS between passes
+template <class KeyT>
+__global__ void __launch_bounds__(256) sort_one_tile_kernel(const KeyT* kin, const uint32_t* vin, KeyT* kout,
+                                                            uint32_t* vout, uint32_t n, int bit_lo, int passes)
+{
+    __shared__ SortShared s;
+    __shared__ KeyT skey[kSortTile];
+    __shared__ uint32_t sval[kSortTile];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    KeyT key[kSortItems];
+    uint32_t val[kSortItems];
+    uint32_t rank[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
+        bool valid = off < n;
+        key[k] = valid ? kin[off] : (KeyT)0;
+        val[k] = (valid && vin) ? vin[off] : 0u;
+    }
+    for (int p = 0; p < passes; ++p) {
+        const int shift = bit_lo + 8 * p;
+        (void)tile_rank<KeyT>(s, key, n, shift, rank);
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) {
+            uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
+            if (off < n) {
+                uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+                uint32_t lp = s.dstart[d] + s.cnt[w][d] + rank[k];
+                skey[lp] = key[k];
+                sval[lp] = val[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) {
+            uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
+            if (off < n) { key[k] = skey[off]; val[k] = sval[off]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
+        if (off < n) {
+            kout[off] = key[k];
+            if (vout) vout[off] = val[k];
         }
     }
 }
@@ -331,31 +480,46 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const KeyT* kin, cons
 inline size_t sort_temp_words(uint64_t n)
 {
     uint64_t ntiles = (n + kSortTile - 1) / kSortTile;
-    return (size_t)(256 * ntiles) + scan_temp_words(256 * ntiles) + 16;
+    return (size_t)kMaxSortPasses * (256 + 256 * ntiles) + 64;
 }
 
-// Sorts (keys[, vals]) by key bits [bit_lo, bit_hi), stable.  k[0]/v[0] hold the
-// input; returns the index (0 or 1) of the buffers holding the result.
+// Sorts (keys[, vals]) by key bits [bit_lo, bit_lo + 8 * ceil((bit_hi - bit_lo) / 8)),
+// stable.  k[0]/v[0] hold the input; returns the index (0 or 1) of the buffers holding
+// the result.  temp: sort_temp_words(n) words.
 template <class KeyT>
 inline int radix_sort_pairs(Stream st, KeyT* k[2], uint32_t* v[2], uint64_t n, int bit_lo, int bit_hi,
                             uint32_t* temp)
 {
-    if (n > 0xfffffff0ull) throw std::runtime_error("radix_sort: too many items");
-    int cur = 0;
-    if (n <= 1) return cur;
-    uint32_t ntiles = (uint32_t)((n + kSortTile - 1) / kSortTile);
-    uint32_t* hist = temp;
-    uint32_t* scan_tmp = temp + (size_t)256 * ntiles;
-    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_hist_kernel<KeyT>), dim3(ntiles), dim3(256), 0, st, k[cur],
-                           (uint32_t)n, shift, ntiles, hist);
-        exclusive_scan_u32(st, hist, hist, (uint64_t)256 * ntiles, scan_tmp, nullptr);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_scatter_kernel<KeyT>), dim3(ntiles), dim3(256), 0, st, k[cur],
-                           v ? v[cur] : nullptr, k[cur ^ 1], v ? v[cur ^ 1] : nullptr, (uint32_t)n, shift, ntiles,
-                           hist);
+    if (n >= (1ull << 30)) throw std::runtime_error("radix_sort: too many items");
+    if (n <= 1 || bit_hi <= bit_lo) return 0;
+    const int passes = (bit_hi - bit_lo + 7) / 8;
+    if (passes > kMaxSortPasses) throw std::runtime_error("radix_sort: too many digit passes");
+    const int result = passes & 1;
+    if (n <= (uint64_t)kSortTile) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_one_tile_kernel<KeyT>), dim3(1), dim3(256), 0, st, k[0],
+                           v ? v[0] : nullptr, k[result], v ? v[result] : nullptr, (uint32_t)n, bit_lo, passes);
         PSIM_HIP(hipGetLastError());
+        return result;
+    }
+    const uint32_t ntiles = (uint32_t)((n + kSortTile - 1) / kSortTile);
+    // temp layout: digit counts [passes][256] | tile counters [64] | status [passes][ntiles][256]
+    uint32_t* digit_counts = temp;
+    uint32_t* next_tile = temp + (size_t)kMaxSortPasses * 256;
+    uint32_t* status = next_tile + 64;
+    dev_memset(st, temp, 0, ((size_t)kMaxSortPasses * 256 + 64 + (size_t)passes * ntiles * 256) * sizeof(uint32_t));
+    uint32_t count_blocks = ntiles < 2048u ? ntiles : 2048u;
+    uint32_t per_block = (uint32_t)((n + count_blocks - 1) / count_blocks);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_digit_counts_kernel<KeyT>), dim3(count_blocks), dim3(256), 0, st, k[0],
+                       (uint32_t)n, bit_lo, passes, per_block, digit_counts);
+    uint32_t* fault = sort_fault_word();
+    int cur = 0;
+    for (int p = 0; p < passes; ++p) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_pass_kernel<KeyT>), dim3(ntiles), dim3(256), 0, st, k[cur],
+                           v ? v[cur] : nullptr, k[cur ^ 1], v ? v[cur ^ 1] : nullptr, (uint32_t)n, bit_lo + 8 * p,
+                           digit_counts + p * 256, status + (size_t)p * ntiles * 256, next_tile + p, fault);
         cur ^= 1;
     }
+    PSIM_HIP(hipGetLastError());
     return cur;
 }
 
@@ -447,18 +611,23 @@ inline void reduce3_sum_f64(Stream st, const double* a, const double* b, const d
 namespace psim {
 namespace be {
 
-// 1/sqrt(x): the hardware estimate (v_rsq_f64, about 2^-29 relative) plus one
-// Newton step, y (1 + e/2) with e = 1 - x y^2: about 2^-56 relative.
-__device__ __forceinline__ double rsqrt_refined(double x)
+// m (x)^-3/2 from the hardware estimate y = v_rsq_f64(x) (about 2^-29 relative) and one
+// Newton correction folded into the cube: with e = 1 - x y^2, x^-1/2 = y (1 + e/2 + ...),
+// so x^-3/2 = y^3 (1 + 3e/2) up to terms of order e^2 < 2^-56.
+__device__ __forceinline__ double mass_inv_r3(double m, double x)
 {
     double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-(x * y), y, 1.0);
-    return fma(y * e, 0.5, y);
+    double y2 = y * y;
+    double e = fma(-x, y2, 1.0);
+    double f0 = (m * y) * y2;
+    return f0 * fma(1.5, e, 1.0);
 }
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-template <bool COUNT>
+// FOLD: theta^2 is a power of two, so w^2 < theta^2 d^2 is decided exactly as
+// (w^2 / theta^2) < d^2 and the caller passes w2_root already divided by theta^2.
+template <bool COUNT, bool FOLD>
 __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
@@ -489,18 +658,23 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
         // internal: accept iff w^2 < theta^2 d^2 (which implies d^2 > 0 since w^2 > 0);
         // leaf: interact iff 0 < d^2.  One compare serves both: lhs < scale * d^2.
         const double lhs = leaf ? 0.0 : __longlong_as_double((long long)(w2_bits - ((uint64_t)(depth & 31u) << 53)));
-        const double scale = leaf ? 1.0 : theta2;
         const bool active = until <= ju;
         const double dx = rv.y - px, dy = rv.z - py;
         const double d2 = fma(dx, dx, dy * dy);
-        const bool take = active && (lhs < scale * d2);
+        bool accept;
+        if (FOLD) {
+            accept = lhs < d2;
+        } else {
+            const double scale = leaf ? 1.0 : theta2;
+            accept = lhs < scale * d2;
+        }
+        const bool take = active && accept;
         if (COUNT) {
             const unsigned long long take_mask = __builtin_amdgcn_ballot_w64(take);
             visits += active ? 1u : 0u; inter += take ? 1u : 0u; trips += 1u; force_trips += take_mask ? 1u : 0u;
         }
         if (take) {                                          // skipped as a whole when no lane accepts
-            double ri = rsqrt_refined(d2 + softening);
-            double f = (rv.x * ri) * (ri * ri);
+            double f = mass_inv_r3(rv.x, d2 + softening);
             ax = fma(f, dx, ax);
             ay = fma(f, dy, ay);
             until = jb;
@@ -527,6 +701,32 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
             atomicAdd(&counters[3], (unsigned long long)force_trips);
         }
     }
+}
+
+// theta^2 = 2^k exactly (theta = 0.5, the reference's default, gives 2^-2)?
+inline bool is_power_of_two(double v)
+{
+    int e = 0;
+    return v > 0.0 && frexp(v, &e) == 0.5 && e > -500 && e < 500;
+}
+
+template <bool COUNT>
+inline void launch_walk(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
+                        const vec2* spos, const double* smass, const uint32_t* perm, const double* inv_mass, vec2* out,
+                        double w2_root, double theta2, double g_const, double softening, unsigned long long* counters)
+{
+    if (hi <= lo) return;
+    int64_t blocks = (hi - lo + 255) / 256;
+    if (blocks > 0x7fffffffLL) throw std::runtime_error("launch_walk: grid too large");
+    if (is_power_of_two(theta2))
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gravity_walk_wave_kernel<COUNT, true>), dim3((unsigned)blocks), dim3(256), 0,
+                           st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_root / theta2, theta2,
+                           g_const, softening, counters);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gravity_walk_wave_kernel<COUNT, false>), dim3((unsigned)blocks), dim3(256), 0,
+                           st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_root, theta2, g_const,
+                           softening, counters);
+    PSIM_HIP(hipGetLastError());
 }
 
 }  // namespace be
@@ -593,8 +793,7 @@ __global__ void __launch_bounds__(256) brute_force_kernel(int64_t n, const vec2*
         for (int k = 0; k < 256; ++k) {
             double dx = sx[k] - px, dy = sy[k] - py;
             double d2 = fma(dx, dx, dy * dy);
-            double ri = rsqrt_refined(d2 + softening);
-            double f = (sm[k] * ri) * (ri * ri);
+            double f = mass_inv_r3(sm[k], d2 + softening);
             f = d2 > 0.0 ? f : 0.0;
             ax = fma(f, dx, ax);
             ay = fma(f, dy, ay);

@@ -26,13 +26,10 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     double theta2 = cfg.theta * cfg.theta;          // particle_system.py:88 theta * theta * dist_sq
 #if !defined(PSIM_HOSTLOOP)
     if (cfg.walk_mode == 0) {
-        int64_t blocks = (hi - lo + 255) / 256;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(be::gravity_walk_wave_kernel<false>), dim3((unsigned)blocks), dim3(256), 0,
-                           st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
-                           (const double*)smass.p, (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p, out,
-                           cfg.bounds_w * cfg.bounds_w, theta2, cfg.gravity_constant, cfg.softening,
-                           (unsigned long long*)nullptr);
-        PSIM_HIP(hipGetLastError());
+        be::launch_walk<false>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
+                               (const double*)smass.p, (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p,
+                               out, cfg.bounds_w * cfg.bounds_w, theta2, cfg.gravity_constant, cfg.softening,
+                               (unsigned long long*)nullptr);
         return;
     }
 #endif
@@ -269,13 +266,11 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     psim::DevBuf<unsigned long long> cnt;
     cnt.ensure(32);
     psim::be::dev_memset(s->st, cnt.p, 0, 256);
-    int64_t blocks = (s->n + 255) / 256;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(psim::be::gravity_walk_wave_kernel<true>), dim3((unsigned)blocks), dim3(256), 0,
-                       s->st, (int64_t)0, s->n, 0, (const psim::NodeRec*)s->rec.p, total, (const psim::vec2*)s->spos.p,
-                       (const double*)s->smass.p, (const uint32_t*)s->perm[s->sorted_key].p,
-                       (const double*)s->inv_mass.p, scratch.p, s->cfg.bounds_w * s->cfg.bounds_w, theta2,
-                       s->cfg.gravity_constant, s->cfg.softening, cnt.p);
-    PSIM_HIP(hipGetLastError());
+    psim::be::launch_walk<true>(s->st, (int64_t)0, s->n, 0, (const psim::NodeRec*)s->rec.p, total,
+                                (const psim::vec2*)s->spos.p, (const double*)s->smass.p,
+                                (const uint32_t*)s->perm[s->sorted_key].p, (const double*)s->inv_mass.p, scratch.p,
+                                s->cfg.bounds_w * s->cfg.bounds_w, theta2, s->cfg.gravity_constant, s->cfg.softening,
+                                cnt.p);
     unsigned long long h[32];
     psim::be::copy_d2h(s->st, h, cnt.p, 256);
     psim::be::sync(s->st);

@@ -340,15 +340,8 @@ struct TreeEmit {
     }
 };
 
-// quadtree.py:85-114 (_calculate_mass_distribution_jit) for the internal nodes
-// of one depth, children visited in quadrant order 0..3, strict FP64:
-//   total += m_c; num += com_c * m_c (mass <= 0 skipped); com = num / total.
-// Also accumulates this node's sibling-pair potential energy
-// (particle_system.py:43-63) while the four children are in registers.
-struct TreeCom {
-    int64_t count;
-    const uint32_t* ids;       // node ids of this depth
-    int depth;
+// Reads the (up to four) children of internal node `id` in quadrant order.
+struct NodeChildren {
     int64_t n;
     const uint64_t* key;
     const int8_t* L;
@@ -357,12 +350,11 @@ struct TreeCom {
     const double* smass;
     const uint32_t* node_first;
     const uint32_t* node_last;
-    NodeRec* rec;
-    double* pe_node;
-    double g_const, softening;
+    const NodeRec* rec;
+
     // deepest level only: children are the four depth-32 cells, each a bucket of
     // particles that coincide to all 32 levels (the reference never terminates on these)
-    PSIM_HD void children_by_search(uint32_t id, uint32_t s, double* cm, double* cx, double* cy) const
+    PSIM_HD void by_search(uint32_t id, uint32_t s, int depth, double* cm, double* cx, double* cy) const
     {
         uint32_t e = node_last[id];
         int sh = 62 - 2 * depth;
@@ -390,8 +382,7 @@ struct TreeCom {
                     const NodeRec& r = rec[c0 + cid];
                     cm[q] = r.mass; cx[q] = r.x; cy[q] = r.y;
                 } else {
-                    // bucket leaf: particles that coincide to all 32 levels (the
-                    // reference never terminates on these); fold them in order
+                    // bucket leaf: fold its particles in order
                     double tm = 0.0, nx = 0.0, ny = 0.0;
                     for (uint32_t k = c0; k < c0 + cnt; ++k) {
                         double m = smass[k];
@@ -404,11 +395,9 @@ struct TreeCom {
         }
     }
 
-    PSIM_HD void operator()(int64_t t) const
+    PSIM_HD void load(uint32_t id, int depth, double* cm, double* cx, double* cy) const
     {
-        uint32_t id = ids[t];
         uint32_t s = node_first[id];
-        double cm[4], cx[4], cy[4];
         for (int q = 0; q < 4; ++q) { cm[q] = 0.0; cx[q] = 0.0; cy[q] = 0.0; }
         if (depth < kMaxInternalDepth) {
             // the children are the elements of this node's subtree reached by following skip
@@ -422,8 +411,25 @@ struct TreeCom {
                 c = nxt > c ? nxt : c + 1;
             }
         } else {
-            children_by_search(id, s, cm, cx, cy);
+            by_search(id, s, depth, cm, cx, cy);
         }
+    }
+};
+
+// quadtree.py:85-114 (_calculate_mass_distribution_jit) for the internal nodes
+// of one depth, children visited in quadrant order 0..3, strict FP64:
+//   total += m_c; num += com_c * m_c (mass <= 0 skipped); com = num / total.
+struct TreeCom {
+    int64_t count;
+    const uint32_t* ids;       // node ids of this depth
+    int depth;
+    NodeChildren ch;
+    NodeRec* rec;
+    PSIM_HD void operator()(int64_t t) const
+    {
+        uint32_t id = ids[t];
+        double cm[4], cx[4], cy[4];
+        ch.load(id, depth, cm, cx, cy);
         double total = 0.0, nx = 0.0, ny = 0.0;
         for (int q = 0; q < 4; ++q) {
             if (cm[q] > 0) {
@@ -432,9 +438,26 @@ struct TreeCom {
                 ny += cy[q] * cm[q];
             }
         }
-        NodeRec& out = rec[s + id];
+        NodeRec& out = rec[ch.node_first[id] + id];
         out.mass = total;
         if (total > 0) { out.x = nx / total; out.y = ny / total; }
+    }
+};
+
+// particle_system.py:43-63: the sibling-pair potential energy of one internal node
+// (its children taken as point masses at their centres of mass).  Only needed when
+// the energies are asked for, so it is not part of the step.
+struct TreePotential {
+    int64_t count;             // internal nodes
+    NodeChildren ch;
+    double* pe_node;
+    double g_const, softening;
+    PSIM_HD void operator()(int64_t t) const
+    {
+        uint32_t id = (uint32_t)t;
+        int depth = (int)ch.rec[ch.node_first[id] + id].depth;
+        double cm[4], cx[4], cy[4];
+        ch.load(id, depth, cm, cx, cy);
         double pe = 0.0;
         for (int i = 0; i < 4; ++i) {
             if (!(cm[i] > 0)) continue;

@@ -372,14 +372,20 @@ public:
                 int64_t cnt = depth_off_host[d + 1] - depth_off_host[d];
                 if (cnt <= 0) continue;
                 TreeCom t;
-                t.count = cnt; t.ids = node_id[sd].p + depth_off_host[d]; t.depth = d; t.n = n; t.key = skey;
-                t.L = L.p; t.base = base.p; t.spos = spos.p; t.smass = smass.p; t.node_first = node_first.p;
-                t.node_last = node_last.p; t.rec = rec.p; t.pe_node = pe_node.p;
-                t.g_const = cfg.gravity_constant; t.softening = cfg.softening;
+                t.count = cnt; t.ids = node_id[sd].p + depth_off_host[d]; t.depth = d; t.ch = node_children();
+                t.rec = rec.p;
                 be::launch(st, cnt, t);
             }
         }
         tree_valid = true;
+    }
+
+    NodeChildren node_children() const
+    {
+        NodeChildren c;
+        c.n = n; c.key = key[sorted_key].p; c.L = L.p; c.base = base.p; c.spos = spos.p; c.smass = smass.p;
+        c.node_first = node_first.p; c.node_last = node_last.p; c.rec = rec.p;
+        return c;
     }
 
     void gravity(vec2* out);   // defined after the back end's walk kernel (psim_capi.cpp)
@@ -679,7 +685,15 @@ public:
         k.cool_factor = 1.0 - cfg.damping;
         k.do_cool = ((cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0) ? 1 : 0;
         be::launch(st, n, k);
-        return f ? read_u32(counters.p) : 0;
+        if (!f) return 0;
+        // one synchronisation for the explosion count and the sorts' fault word
+        uint32_t two[2];
+        be::copy_d2h(st, pinned, counters.p, 4);
+        be::copy_d2h(st, (char*)pinned + 4, be::sort_fault_word(), 4);
+        be::sync(st);
+        memcpy(two, pinned, 8);
+        if (two[1] != 0) throw std::runtime_error("psim: internal: radix sort look-back timed out");
+        return two[0];
     }
 
     // particle_system.py:651-730
@@ -866,7 +880,11 @@ public:
         } else {
             be::dev_memset(st, red_out.p, 0, 32);
         }
-        if (tree_valid && n_internal > 0) be::reduce_sum_f64(st, pe_node.p, n_internal, red_tmp.p, red_out.p + 4);
+        if (tree_valid && n_internal > 0) {
+            be::launch(st, (int64_t)n_internal, TreePotential{(int64_t)n_internal, node_children(), pe_node.p,
+                                                              cfg.gravity_constant, cfg.softening});
+            be::reduce_sum_f64(st, pe_node.p, n_internal, red_tmp.p, red_out.p + 4);
+        }
         else be::dev_memset(st, red_out.p + 4, 0, 8);
         double t[5];
         readback(t, red_out.p, 40);
