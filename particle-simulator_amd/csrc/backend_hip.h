@@ -118,49 +118,54 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     return r;
 }
 
+constexpr uint32_t kLookSpinLimit = 1u << 26;   // polls before a waiting lane gives up (seconds)
+
+// Word set by a scan or sort kernel whose look-back gave up waiting (it cannot, as
+// every tile a workgroup waits for has already started; the bound only guarantees that
+// the kernels end whatever happens).  One per device; the host reads it with every
+// small readback.  A tile that gives up writes no keys (sort) or zeros (scan).
+inline uint32_t* lookback_fault_word()
+{
+    static uint32_t* words[64] = {};
+    int dev = 0;
+    PSIM_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) throw std::runtime_error("lookback_fault_word: device index out of range");
+    if (!words[dev]) {
+        words[dev] = (uint32_t*)dev_alloc(64);
+        PSIM_HIP(hipMemset(words[dev], 0, 64));
+    }
+    return words[dev];
+}
+
 // ------------------------------------------------------------------ exclusive scan (u32)
 constexpr int kScanItems = 16;
 constexpr int kScanTile = 256 * kScanItems;
 
-__global__ void __launch_bounds__(256) scan_reduce_kernel(const uint32_t* in, uint32_t n, uint32_t* block_sums)
+// One launch for any length: each 256-lane workgroup takes the next 4096-item tile
+// (numbered by an atomic counter), scans it, publishes the tile's sum and finds the
+// sum of everything before it by looking back over its predecessors' status words
+// (64 at a time, one per lane of the first wave): a predecessor shows either its own
+// sum (keep looking) or the running total up to and including itself (stop).  The
+// last workgroup to finish clears the status words, so `temp` only has to be zero
+// before its first use.
+constexpr uint64_t kScanLocal = 1ull << 62, kScanInclusive = 2ull << 62, kScanValue = (1ull << 62) - 1;
+
+__global__ void __launch_bounds__(256) scan_lookback_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
+                                                            uint32_t ntiles, uint32_t* temp, uint32_t* total_out,
+                                                            uint32_t* fault)
 {
     __shared__ uint32_t wsum[8];
-    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t s = 0;
-    if (base + kScanItems <= n) {
-        const uint4* p = reinterpret_cast<const uint4*>(in + base);
-#pragma unroll
-        for (int i = 0; i < kScanItems / 4; ++i) { uint4 v = p[i]; s += v.x + v.y + v.z + v.w; }
-    } else {
-        for (int i = 0; i < kScanItems; ++i) if (base + i < n) s += in[base + i];
-    }
-    uint32_t total;
-    (void)block_exclusive_scan(s, wsum, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-__global__ void __launch_bounds__(1024) scan_spine_kernel(uint32_t* block_sums, uint32_t nb, uint32_t* total_out)
-{
-    __shared__ uint32_t wsum[17];
-    uint32_t per = (nb + 1023) / 1024;
-    uint32_t b0 = threadIdx.x * per;
-    uint32_t s = 0;
-    for (uint32_t i = 0; i < per; ++i) if (b0 + i < nb) s += block_sums[b0 + i];
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan(s, wsum, &total);
-    for (uint32_t i = 0; i < per; ++i)
-        if (b0 + i < nb) { uint32_t t = block_sums[b0 + i]; block_sums[b0 + i] = ex; ex += t; }
-    if (threadIdx.x == 0 && total_out) *total_out = total;
-}
-
-__global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
-                                                         const uint32_t* block_sums)
-{
-    __shared__ uint32_t wsum[8];
-    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    __shared__ uint32_t s_tile, s_failed;
+    __shared__ uint64_t s_before;
+    uint64_t* status = reinterpret_cast<uint64_t*>(temp + 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) { s_tile = atomicAdd(&temp[0], 1u); s_failed = 0; s_before = 0; }
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    uint32_t base = tile * kScanTile + tid * kScanItems;
     uint32_t v[kScanItems];
-    uint32_t s = 0;
-    bool full = base + kScanItems <= n;
+    uint32_t sum = 0;
+    const bool full = base + kScanItems <= n && base + kScanItems > base;
     if (full) {
         const uint4* p = reinterpret_cast<const uint4*>(in + base);
 #pragma unroll
@@ -173,11 +178,68 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, uin
         for (int i = 0; i < kScanItems; ++i) v[i] = (base + i < n) ? in[base + i] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) s += v[i];
+    for (int i = 0; i < kScanItems; ++i) sum += v[i];
     uint32_t total;
-    uint32_t ex = block_exclusive_scan(s, wsum, &total) + block_sums[blockIdx.x];
+    uint32_t ex = block_exclusive_scan(sum, wsum, &total);
+    if (tid < 64) {
+        if (lane == 0)
+            __hip_atomic_store(status + tile, (tile == 0 ? kScanInclusive : kScanLocal) | (uint64_t)total,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t before = 0;
+        bool ok = true;
+        if (tile > 0) {
+            int64_t first = (int64_t)tile - 1;        // lane l looks at tile first - l
+            uint32_t polls = 0;
+            for (;;) {
+                int64_t t = first - lane;
+                uint64_t sv = (t >= 0) ? __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : kScanInclusive;          // before tile 0: nothing
+                uint32_t flag = (uint32_t)(sv >> 62);
+                uint64_t ready = __ballot(flag != 0), incl = __ballot(flag == 2);
+                if (incl != 0) {
+                    int f = __ffsll((long long)incl) - 1;           // nearest predecessor with a running total
+                    uint64_t upto = (f == 63) ? ~0ull : ((1ull << (f + 1)) - 1);
+                    if ((ready & upto) == upto) {
+                        uint64_t mine = (lane <= f) ? (sv & kScanValue) : 0ull;
+                        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+                        before += mine;
+                        break;
+                    }
+                } else if (ready == ~0ull) {
+                    uint64_t mine = sv & kScanValue;
+                    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+                    before += mine;
+                    first -= 64;
+                    continue;
+                }
+                if ((++polls & 63u) == 0 &&
+                    (polls >= kLookSpinLimit ||
+                     __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (lane == 0) {
+            if (ok) {
+                if (tile > 0)
+                    __hip_atomic_store(status + tile, kScanInclusive | ((before + total) & kScanValue), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                s_before = before;
+                if (tile == ntiles - 1 && total_out) *total_out = (uint32_t)(before + total);
+            } else {
+                __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_failed = 1;
+                if (total_out) *total_out = 0u;
+            }
+        }
+    }
+    __syncthreads();
+    const bool failed = s_failed != 0;
+    ex += (uint32_t)s_before;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { uint32_t t = v[i]; v[i] = ex; ex += t; }
+    for (int i = 0; i < kScanItems; ++i) { uint32_t t = v[i]; v[i] = failed ? 0u : ex; ex += t; }
     if (full) {
         uint4* p = reinterpret_cast<uint4*>(out + base);
 #pragma unroll
@@ -185,6 +247,19 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const uint32_t* in, uin
     } else {
 #pragma unroll
         for (int i = 0; i < kScanItems; ++i) if (base + i < n) out[base + i] = v[i];
+    }
+    // the last workgroup to get here clears the scratch for the next scan: by then every
+    // workgroup has finished looking back, so no status word is read any more
+    __syncthreads();
+    if (tid == 0) s_tile = atomicAdd(&temp[1], 1u);
+    __syncthreads();
+    if (s_tile == ntiles - 1) {
+        for (uint32_t i = tid; i < ntiles; i += 256)
+            __hip_atomic_store(status + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(&temp[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&temp[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -205,9 +280,10 @@ __global__ void __launch_bounds__(1024) scan_small_kernel(const uint32_t* in, ui
     if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
-inline size_t scan_temp_words(uint64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile) + 1; }
+inline size_t scan_temp_words(uint64_t n) { return 16 + 2 * (size_t)((n + kScanTile - 1) / kScanTile) + 2; }
 
-// out may alias in.  temp: scan_temp_words(n) words.  total_out: device word or null.
+// out may alias in.  temp: scan_temp_words(n) words, ZERO before its first use (each scan
+// leaves it zero again).  total_out: device word or null.
 inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* temp,
                                uint32_t* total_out)
 {
@@ -219,10 +295,8 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
         return;
     }
     uint32_t nb = (uint32_t)((n + kScanTile - 1) / kScanTile);
-    if (nb > 1024u * 64u) throw std::runtime_error("exclusive_scan_u32: spine too long");
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(256), 0, st, in, (uint32_t)n, temp);
-    hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(1024), 0, st, temp, nb, total_out);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, st, in, out, (uint32_t)n, temp);
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3(nb), dim3(256), 0, st, in, out, (uint32_t)n, nb, temp, total_out,
+                       lookback_fault_word());
     PSIM_HIP(hipGetLastError());
 }
 
@@ -243,22 +317,6 @@ constexpr int kMaxSortPasses = 8;
 constexpr uint32_t kLookValue = 0x3fffffffu;
 constexpr uint32_t kLookLocal = 1u << 30;       // this tile's own count
 constexpr uint32_t kLookInclusive = 2u << 30;   // count of this tile and every tile before it
-constexpr uint32_t kLookSpinLimit = 1u << 26;   // polls before a waiting lane gives up (seconds)
-
-// word set by a pass kernel whose look-back gave up; one per device, read by the host
-// once per step.  A tile that gives up writes nothing, so a failed sort stays in bounds.
-inline uint32_t* sort_fault_word()
-{
-    static uint32_t* words[64] = {};
-    int dev = 0;
-    PSIM_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) throw std::runtime_error("sort_fault_word: device index out of range");
-    if (!words[dev]) {
-        words[dev] = (uint32_t*)dev_alloc(64);
-        PSIM_HIP(hipMemset(words[dev], 0, 64));
-    }
-    return words[dev];
-}
 
 struct SortShared {
     uint32_t cnt[4][256];
@@ -511,7 +569,7 @@ inline int radix_sort_pairs(Stream st, KeyT* k[2], uint32_t* v[2], uint64_t n, i
     uint32_t per_block = (uint32_t)((n + count_blocks - 1) / count_blocks);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_digit_counts_kernel<KeyT>), dim3(count_blocks), dim3(256), 0, st, k[0],
                        (uint32_t)n, bit_lo, passes, per_block, digit_counts);
-    uint32_t* fault = sort_fault_word();
+    uint32_t* fault = lookback_fault_word();
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_pass_kernel<KeyT>), dim3(ntiles), dim3(256), 0, st, k[cur],

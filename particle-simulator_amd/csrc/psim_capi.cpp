@@ -463,7 +463,7 @@ int psim_selftest(int device_ordinal, int64_t n, uint64_t seed)
         // --- exclusive scan
         std::vector<uint32_t> hs(c), gs(c);
         for (size_t i = 0; i < c; ++i) hs[i] = (uint32_t)(rng() % 5);
-        stmp.ensure(be::scan_temp_words(c));
+        stmp.ensure_zero(st, be::scan_temp_words(c));
         DevBuf<uint32_t> tot;
         tot.ensure(1);
         be::copy_h2d(st, a0.p, hs.data(), c * 4);
@@ -475,6 +475,14 @@ int psim_selftest(int device_ordinal, int64_t n, uint64_t seed)
         uint32_t run = 0;
         for (size_t i = 0; i < c; ++i) { if (gs[i] != run) throw std::runtime_error("selftest: scan mismatch at " + std::to_string(i)); run += hs[i]; }
         if (gtot != run) throw std::runtime_error("selftest: scan total mismatch");
+        // again, in place, on the scratch the first scan left behind
+        be::exclusive_scan_u32(st, a0.p, a0.p, (uint64_t)n, stmp.p, tot.p);
+        be::copy_d2h(st, gs.data(), a0.p, c * 4);
+        be::copy_d2h(st, &gtot, tot.p, 4);
+        be::sync(st);
+        run = 0;
+        for (size_t i = 0; i < c; ++i) { if (gs[i] != run) throw std::runtime_error("selftest: in-place scan mismatch at " + std::to_string(i)); run += hs[i]; }
+        if (gtot != run) throw std::runtime_error("selftest: in-place scan total mismatch");
         // --- reduction (integers stored as doubles: exact in any order)
         std::vector<double> hd(c);
         double want = 0.0;

@@ -272,12 +272,14 @@ struct TreeLinks {
     }
 };
 
-PSIM_HD PSIM_FORCEINLINE uint32_t range_last(const uint64_t* key, uint32_t s, uint32_t n, int d)
+// Last sorted particle sharing its first d levels with particle s; `from` is an index
+// already known to lie inside that range (s itself if nothing better is known).
+PSIM_HD PSIM_FORCEINLINE uint32_t range_last(const uint64_t* key, uint32_t s, uint32_t n, int d, uint32_t from)
 {
     if (d == 0) return n - 1;
     int sh = 64 - 2 * d;
     uint64_t pre = key[s] >> sh;
-    uint32_t lo = s, hi;
+    uint32_t lo = from, hi;
     uint32_t step = 1;
     for (;;) {
         uint64_t t = (uint64_t)lo + step;
@@ -310,24 +312,41 @@ struct TreeEmit {
     uint32_t* node_last;
     uint32_t* node_depth;      // u32 so it can be a radix-sort key
     uint32_t* node_id;
+    // The cell of depth d that starts at s ends just before the first t > s with L[t-1] < d,
+    // and deeper cells end no later than shallower ones: one forward scan over L closes the
+    // owned cells deepest first.  Most cells hold a handful of particles; after kScan steps
+    // the (few, large) cells still open are finished by a galloping search on the keys.
+    static constexpr int kScan = 24;
+    PSIM_HD void emit_node(int64_t s, uint32_t b, int lp, int d, uint32_t e) const
+    {
+        uint32_t id = b + (uint32_t)(d - lp - 1);
+        uint32_t skip = (e + 1 < (uint32_t)n) ? (e + 1) + base[e + 1] : total_elems;
+        NodeRec r;
+        r.mass = 0.0; r.x = 0.0; r.y = 0.0;
+        r.skip = skip;
+        r.depth = (uint32_t)d;
+        rec[(uint32_t)s + id] = r;
+        node_first[id] = (uint32_t)s;
+        node_last[id] = e;
+        node_depth[id] = (uint32_t)d;
+        node_id[id] = id;
+    }
     PSIM_HD void operator()(int64_t s) const
     {
         uint32_t b = base[s], own = owned[s];
         int lp = (s > 0) ? (int)L[s - 1] : -1;
-        for (uint32_t k = 0; k < own; ++k) {
-            int d = lp + 1 + (int)k;
-            uint32_t id = b + k;
-            uint32_t e = range_last(key, (uint32_t)s, (uint32_t)n, d);
-            uint32_t skip = (e + 1 < (uint32_t)n) ? (e + 1) + base[e + 1] : total_elems;
-            NodeRec r;
-            r.mass = 0.0; r.x = 0.0; r.y = 0.0;
-            r.skip = skip;
-            r.depth = (uint32_t)d;
-            rec[(uint32_t)s + id] = r;
-            node_first[id] = (uint32_t)s;
-            node_last[id] = e;
-            node_depth[id] = (uint32_t)d;
-            node_id[id] = id;
+        if (own > 0) {
+            int d = lp + (int)own;              // deepest owned cell (= L[s]); ends at t >= s + 1
+            uint32_t t = (uint32_t)s;
+            for (int step = 0; step < kScan && d > lp; ++step) {
+                ++t;                            // L[n-1] = -1 closes every cell at the last particle
+                int m = (int)L[t];
+                while (d > lp && d > m) { emit_node(s, b, lp, d, t); --d; }
+            }
+            for (; d > lp; --d) {
+                t = range_last(key, (uint32_t)s, (uint32_t)n, d, t);
+                emit_node(s, b, lp, d, t);
+            }
         }
         uint32_t le = (uint32_t)s + b + own;
         NodeRec r;
@@ -668,14 +687,16 @@ PSIM_HD PSIM_FORCEINLINE void for_each_slot_in_cell(const GridView& g, uint32_t 
 // Sweep 0: test every candidate pair against the sweep's initial positions and
 // collect the keys of those in contact (unordered between lanes; sorted
 // afterwards).  Two passes around an exclusive scan instead of an atomic
-// cursor: pass 0 stores how many contacts each slot found as the lower-index
-// particle, pass 1 (only slots with a non-zero count redo their tests) writes the
-// keys at the scanned offsets.
+// cursor: pass 0 stores how many contacts each slot found and the first one's
+// two slots; pass 1 writes that pair's key at its scanned offset, and only the
+// slots that found two or more redo their tests.
 struct ContactDetect {
     int64_t n;
     GridView g;
     uint32_t* counts;          // pass 0: written; pass 1: read
     const uint32_t* offsets;   // pass 1: exclusive scan of counts
+    uint64_t* first_pair;      // pass 0: the two slots of a slot's first contact (the key's field
+                               // widths are only known after pass 0); pass 1: read
     uint64_t* out_keys;        // pass 1
     int32_t write_pass;
     uint32_t* cand_counter;    // optional (pass 0): number of candidate pairs
@@ -699,6 +720,7 @@ struct ContactDetect {
             ++ncand;
             if (in_contact(P, body_pos(o), me.r, o.r)) {
                 if (WRITE) out_keys[at + found] = make_pair_key(g, c, 0, a, (uint32_t)b - (uint32_t)g.offsets[c]);
+                else if (found == 0) first_pair[k] = ((uint64_t)k << 32) | (uint64_t)(uint32_t)b;
                 ++found;
             } else if (!WRITE && coincident(P, body_pos(o))) {
                 aggregated_inc(coincident_counter);
@@ -719,6 +741,7 @@ struct ContactDetect {
                     if (WRITE)
                         out_keys[at + found] = lower ? make_pair_key(g, c, neighbour_phase(dy, dx), a, (uint32_t)(b - o0))
                                                      : make_pair_key(g, nc, neighbour_phase(-dy, -dx), (uint32_t)(b - o0), a);
+                    else if (found == 0) first_pair[k] = ((uint64_t)k << 32) | (uint64_t)(uint32_t)b;
                     ++found;
                 } else if (!WRITE && coincident(P, body_pos(o))) {
                     aggregated_inc(coincident_counter);
@@ -733,7 +756,13 @@ struct ContactDetect {
     PSIM_HD void operator()(int64_t kk) const
     {
         if (write_pass) {
-            if (counts[kk] != 0) run<true>((uint32_t)kk);
+            uint32_t c = counts[kk];
+            if (c == 1) {
+                uint64_t fp = first_pair[kk];
+                out_keys[offsets[kk]] = pair_key(g, (uint32_t)(fp >> 32), (uint32_t)fp);
+            } else if (c > 1) {
+                run<true>((uint32_t)kk);
+            }
         } else {
             run<false>((uint32_t)kk);
         }
@@ -936,7 +965,8 @@ struct SegDisplacement {
 // 10 + cell selector (the nine cells of one touched slot are re-tested by
 // different lanes); only the first entry of a slot's segment works.  A pair of
 // two touched slots is emitted once, by the slot whose particle index is lower.
-// Two passes around a scan, like ContactDetect: counts[t] then keys at offsets[t].
+// Two passes around a scan, like ContactDetect: counts[t] and the first hit's key,
+// then keys at offsets[t] (elements with two or more hits redo their tests).
 struct ContactRetest {
     int64_t n_adj;
     GridView g;
@@ -948,11 +978,16 @@ struct ContactRetest {
     const double* dseg;
     uint32_t* counts;
     const uint32_t* offsets;
+    uint64_t* first_key;       // count pass: key of an element's first hit
     uint64_t* out_keys;
     int32_t write_pass;
     PSIM_HD void operator()(int64_t t) const
     {
-        if (write_pass && counts[t] == 0) return;
+        if (write_pass) {
+            uint32_t c = counts[t];
+            if (c == 0) return;
+            if (c == 1) { out_keys[offsets[t]] = first_key[t]; return; }
+        }
         int64_t e = t / 10;
         int which = (int)(t - e * 10);
         uint32_t x = (uint32_t)(adj[e] >> 32);
@@ -980,6 +1015,7 @@ struct ContactRetest {
                 bool hit = (px < py) ? in_contact(X, Y, rx, ry) : in_contact(Y, X, ry, rx);
                 if (hit) {
                     if (write_pass) out_keys[at + found] = tk;
+                    else if (found == 0) first_key[t] = tk;
                     ++found;
                 }
             });

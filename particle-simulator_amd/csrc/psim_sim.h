@@ -42,6 +42,15 @@ struct DevBuf {
             cap = want;
         }
     }
+    // like ensure(), and a newly allocated buffer is cleared (on stream s)
+    template <class StreamT>
+    void ensure_zero(StreamT s, size_t n)
+    {
+        if (n > cap) {
+            ensure(n);
+            be::dev_memset(s, p, 0, cap * sizeof(T));
+        }
+    }
     void swap(DevBuf& o) { std::swap(p, o.p); std::swap(cap, o.cap); }
 };
 
@@ -104,6 +113,7 @@ public:
     size_t ccap = 0;
     DevBuf<uint64_t> h0[2], hc[2], hn[2], adj[2];
     DevBuf<uint32_t> hsi, hsj, done, pcount, poffs, moved_list;
+    DevBuf<uint64_t> first_key;
     DevBuf<uint8_t> moved;
     DevBuf<double> cdelta;
     DevBuf<uint64_t> cond_entries[2];
@@ -231,10 +241,14 @@ public:
     // small synchronous readback through the page-locked staging block
     void readback(void* dst, const void* dev, size_t bytes)
     {
-        if (bytes > kPinnedBytes) throw std::runtime_error("psim: internal: readback too large");
+        if (bytes + 8 > kPinnedBytes) throw std::runtime_error("psim: internal: readback too large");
         be::copy_d2h(st, pinned, dev, bytes);
+        // every readback also fetches the word a scan / sort look-back sets if it gave up
+        uint32_t* fault = (uint32_t*)((char*)pinned + kPinnedBytes - 8);
+        be::copy_d2h(st, fault, be::lookback_fault_word(), 4);
         be::sync(st);
         memcpy(dst, pinned, bytes);
+        if (*fault != 0) throw std::runtime_error("psim: internal: scan / sort look-back timed out");
     }
     uint32_t read_u32(const uint32_t* d)
     {
@@ -294,10 +308,10 @@ public:
         size_t c = (size_t)n;
         const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
         GridView g = grid_view();
-        pcount.ensure(c); poffs.ensure(c); scan_scratch.ensure(be::scan_temp_words(c));
+        pcount.ensure(c); poffs.ensure(c); first_key.ensure(c); scan_scratch.ensure_zero(s, be::scan_temp_words(c));
         be::dev_memset(s, ctr, 0, 64);
         ContactDetect d;
-        d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
+        d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
         d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? ctr + 1 : nullptr;
         d.coincident_counter = ctr + 3;
         be::launch(s, n, d);
@@ -319,7 +333,7 @@ public:
         uint64_t* k[2] = {key[0].p, key[1].p};
         uint32_t* v[2] = {perm[0].p, perm[1].p};
         spos.ensure(c); smass.ensure(c); L.ensure(c); owned.ensure(c); base.ensure(c);
-        scan_tmp.ensure(be::scan_temp_words(c));
+        scan_tmp.ensure_zero(st, be::scan_temp_words(c));
         uint32_t m = 0;
         const uint64_t* skey = nullptr;
         const uint32_t* sperm = nullptr;
@@ -439,7 +453,8 @@ public:
                 detect_count(st, scan_tmp, counters.p);
             }
             ContactDetect d;
-            d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.coincident_counter = nullptr;
+            d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
+            d.coincident_counter = nullptr;
             uint32_t three[4];
             readback(three, ctr, 16);
             n0 = three[0]; cand = three[1];
@@ -498,14 +513,14 @@ public:
             uint32_t nNew = 0;
             {
                 int64_t nt = 20ll * nH, ntot = nt + n0;
-                pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot);
-                scan_tmp.ensure(be::scan_temp_words((uint64_t)ntot));
+                pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)ntot);
+                scan_tmp.ensure_zero(st, be::scan_temp_words((uint64_t)ntot));
                 dseg.ensure(2 * (size_t)nH);
                 be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p});
                 ContactRetest r;
                 r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outst.p;
                 r.dseg = dseg.p;
-                r.counts = pcount.p; r.offsets = poffs.p; r.out_keys = nullptr;
+                r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
                 ContactCarryClean cc{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
                 for (;;) {
@@ -650,7 +665,7 @@ public:
         be::dev_memset(st, cdelta.p, 0, c * 8);
         if (n_moved == 0) return;
         int64_t nt = 10ll * n_moved;
-        pcount.ensure((size_t)nt); poffs.ensure((size_t)nt); scan_tmp.ensure(be::scan_temp_words((uint64_t)nt));
+        pcount.ensure((size_t)nt); poffs.ensure((size_t)nt); scan_tmp.ensure_zero(st, be::scan_temp_words((uint64_t)nt));
         ConductionPairs k;
         k.n_moved = n_moved; k.g = g; k.list = moved_list.p; k.moved = moved.p; k.counts = pcount.p; k.offsets = poffs.p;
         k.entries = nullptr; k.write_pass = 0;
@@ -689,7 +704,7 @@ public:
         // one synchronisation for the explosion count and the sorts' fault word
         uint32_t two[2];
         be::copy_d2h(st, pinned, counters.p, 4);
-        be::copy_d2h(st, (char*)pinned + 4, be::sort_fault_word(), 4);
+        be::copy_d2h(st, (char*)pinned + 4, be::lookback_fault_word(), 4);
         be::sync(st);
         memcpy(two, pinned, 8);
         if (two[1] != 0) throw std::runtime_error("psim: internal: radix sort look-back timed out");
@@ -701,7 +716,7 @@ public:
     {
         size_t c = (size_t)n;
         GridView g = grid_view();
-        tmp32.ensure(c); tmp32b.ensure(c); scan_tmp.ensure(be::scan_temp_words(c));
+        tmp32.ensure(c); tmp32b.ensure(c); scan_tmp.ensure_zero(st, be::scan_temp_words(c));
         ex_list.ensure(count); ex_count.ensure(count); ex_energy.ensure(count); ex_total.ensure(count);
         be::launch(st, n, FlagToU32{n, boom.p, tmp32.p, 0});
         be::exclusive_scan_u32(st, tmp32.p, tmp32b.p, (uint64_t)n, scan_tmp.p, nullptr);

@@ -51,7 +51,7 @@ inline void exclusive_scan_u32(Stream, const uint32_t* in, uint32_t* out, uint64
 }
 
 inline size_t sort_temp_words(uint64_t) { return 1; }
-inline uint32_t* sort_fault_word() { static uint32_t zero = 0; return &zero; }
+inline uint32_t* lookback_fault_word() { static uint32_t zero = 0; return &zero; }
 template <class KeyT>
 inline int radix_sort_pairs(Stream, KeyT* k[2], uint32_t* v[2], uint64_t n, int bit_lo, int bit_hi, uint32_t*)
 {

@@ -20,7 +20,7 @@ def test_library_is_the_hip_build():
     assert b"HIP gfx950" in L.psim_version()
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 2047, 2048, 2049, 100003, 1 << 20])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 2047, 2048, 2049, 16384, 16385, 100003, 1 << 20, (1 << 22) + 77])
 def test_device_primitives(n):
     """radix sort (u64 full range with duplicates, u32 sub-range, stable with
     payload), exclusive scan, ordered reduction vs host results"""
