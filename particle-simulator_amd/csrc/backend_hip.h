@@ -45,8 +45,12 @@ inline void sync(Stream st) { PSIM_HIP(hipStreamSynchronize(st)); }
 // a second, non-blocking stream + events: memory-bound stages overlap the FP64-bound walk
 inline Stream stream_create()
 {
+    // highest priority: the short memory-bound kernels put here get wave slots as the long
+    // FP64-bound walk frees them, instead of waiting behind its whole grid
+    int least = 0, greatest = 0;
+    PSIM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     hipStream_t s = nullptr;
-    PSIM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    PSIM_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
     return s;
 }
 inline void stream_destroy(Stream s) { if (s) (void)hipStreamDestroy(s); }
@@ -139,9 +143,9 @@ inline uint32_t* lookback_fault_word()
 
 // ------------------------------------------------------------------ exclusive scan (u32)
 constexpr int kScanItems = 16;
-constexpr int kScanTile = 256 * kScanItems;
+constexpr int kScanTile = 1024 * kScanItems;
 
-// One launch for any length: each 256-lane workgroup takes the next 4096-item tile
+// One launch for any length: each 1024-lane workgroup takes the next 16384-item tile
 // (numbered by an atomic counter), scans it, publishes the tile's sum and finds the
 // sum of everything before it by looking back over its predecessors' status words
 // (64 at a time, one per lane of the first wave): a predecessor shows either its own
@@ -150,11 +154,11 @@ constexpr int kScanTile = 256 * kScanItems;
 // before its first use.
 constexpr uint64_t kScanLocal = 1ull << 62, kScanInclusive = 2ull << 62, kScanValue = (1ull << 62) - 1;
 
-__global__ void __launch_bounds__(256) scan_lookback_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
+__global__ void __launch_bounds__(1024) scan_lookback_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
                                                             uint32_t ntiles, uint32_t* temp, uint32_t* total_out,
                                                             uint32_t* fault)
 {
-    __shared__ uint32_t wsum[8];
+    __shared__ uint32_t wsum[17];
     __shared__ uint32_t s_tile, s_failed;
     __shared__ uint64_t s_before;
     uint64_t* status = reinterpret_cast<uint64_t*>(temp + 16);
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(256) scan_lookback_kernel(const uint32_t* in, 
     if (tid == 0) { s_tile = atomicAdd(&temp[0], 1u); s_failed = 0; s_before = 0; }
     __syncthreads();
     const uint32_t tile = s_tile;
-    uint32_t base = tile * kScanTile + tid * kScanItems;
+    uint32_t base = tile * kScanTile + tid * kScanItems;   // n < 2^32 - 16: no wrap inside a valid tile
     uint32_t v[kScanItems];
     uint32_t sum = 0;
     const bool full = base + kScanItems <= n && base + kScanItems > base;
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(256) scan_lookback_kernel(const uint32_t* in, 
     if (tid == 0) s_tile = atomicAdd(&temp[1], 1u);
     __syncthreads();
     if (s_tile == ntiles - 1) {
-        for (uint32_t i = tid; i < ntiles; i += 256)
+        for (uint32_t i = tid; i < ntiles; i += 1024)
             __hip_atomic_store(status + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {
             __hip_atomic_store(&temp[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -295,7 +299,7 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
         return;
     }
     uint32_t nb = (uint32_t)((n + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(scan_lookback_kernel, dim3(nb), dim3(256), 0, st, in, out, (uint32_t)n, nb, temp, total_out,
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3(nb), dim3(1024), 0, st, in, out, (uint32_t)n, nb, temp, total_out,
                        lookback_fault_word());
     PSIM_HIP(hipGetLastError());
 }
@@ -619,6 +623,25 @@ __global__ void __launch_bounds__(256) reduce3_small_kernel(const double* a, con
     }
     if (threadIdx.x == 0) out3[blockIdx.x] = s[0];
 }
+// the same for longer arrays: 64 blocks per array write partial sums, then
+// reduce3_small_kernel folds the three lists of 64
+__global__ void __launch_bounds__(256) reduce3_partial_kernel(const double* a, const double* b, const double* c,
+                                                              uint64_t n, uint64_t chunk, double* partial)
+{
+    __shared__ double s[256];
+    const double* in = blockIdx.y == 0 ? a : blockIdx.y == 1 ? b : c;
+    uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk;
+    if (hi > n) hi = n;
+    double acc = 0.0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) acc += in[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.y * 64 + blockIdx.x] = s[0];
+}
 inline void reduce3_sum_f64(Stream st, const double* a, const double* b, const double* c, uint64_t n, double* temp,
                             double* out3);
 
@@ -644,14 +667,16 @@ inline void reduce3_sum_f64(Stream st, const double* a, const double* b, const d
                             double* out3)
 {
     if (n == 0) { dev_memset(st, out3, 0, 24); return; }
-    if (n <= (1u << 18)) {
+    if (n <= 4096) {
         hipLaunchKernelGGL(reduce3_small_kernel, dim3(3), dim3(256), 0, st, a, b, c, n, out3);
         PSIM_HIP(hipGetLastError());
         return;
     }
-    reduce_sum_f64(st, a, n, temp, out3);
-    reduce_sum_f64(st, b, n, temp, out3 + 1);
-    reduce_sum_f64(st, c, n, temp, out3 + 2);
+    uint64_t chunk = (n + 63) / 64;
+    hipLaunchKernelGGL(reduce3_partial_kernel, dim3(64, 3), dim3(256), 0, st, a, b, c, n, chunk, temp);
+    hipLaunchKernelGGL(reduce3_small_kernel, dim3(3), dim3(256), 0, st, (const double*)temp, (const double*)(temp + 64),
+                       (const double*)(temp + 128), (uint64_t)64, out3);
+    PSIM_HIP(hipGetLastError());
 }
 }  // namespace be
 }  // namespace psim

@@ -126,9 +126,9 @@ struct SegmentOffsets {
     }
 };
 
-// largest cell population, in two launches without same-address atomics:
-// WaveMaxOccupancy (over cells rounded up to whole waves) stores one maximum per 64
-// cells, FinalMax (one wave) folds those.
+// largest cell population without same-address atomics: WaveMaxOccupancy (over cells
+// rounded up to whole waves) stores one maximum per 64 cells, WaveMaxU32 folds such a
+// list 64-fold per launch, FinalMax (one wave) folds what is left.
 struct WaveMaxOccupancy {
     int64_t cells;
     const int32_t* offsets;
@@ -145,6 +145,25 @@ struct WaveMaxOccupancy {
             occ = t > occ ? t : occ;
         }
         if ((c & 63) == 0) wave_max[c >> 6] = occ;
+#endif
+    }
+};
+struct WaveMaxU32 {        // launched over count rounded up to whole waves
+    int64_t count;
+    const uint32_t* in;
+    uint32_t* out;             // [ceil(count / 64)]
+    PSIM_HD void operator()(int64_t c) const
+    {
+        uint32_t v = c < count ? in[c] : 0u;
+#if defined(PSIM_HOSTLOOP)
+        if ((c & 63) == 0) out[c >> 6] = 0;
+        if (v > out[c >> 6]) out[c >> 6] = v;
+#else
+        for (int o = 32; o > 0; o >>= 1) {
+            uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+            v = t > v ? t : v;
+        }
+        if ((c & 63) == 0) out[c >> 6] = v;
 #endif
     }
 };
@@ -206,12 +225,12 @@ struct GatherTree {
     }
 };
 
-// Second half of the Morton sort.  The radix passes order the keys by their high
-// 32 bits only (the 16 coarsest levels); particles that share those are rare and
-// form short runs, which the lane at each run's start finishes by ranking on the
-// full key (ties keep input order, like the stable radix passes).  A run longer
-// than kMaxFixRun is copied as is and reported, and the caller completes the sort
-// with the remaining radix passes.
+// Second half of the Morton sort.  The radix passes order the keys by their leading
+// bits only (key >> shift: enough levels that few particles share them); particles
+// that do share them form short runs, which the lane at each run's start finishes by
+// ranking on the full key (ties keep input order, like the stable radix passes).  A
+// run longer than kMaxFixRun is copied as is and reported, and the caller completes
+// the sort with the remaining radix passes.
 constexpr uint32_t kMaxFixRun = 48;
 struct FixRuns {
     int64_t n;
@@ -220,13 +239,14 @@ struct FixRuns {
     uint64_t* key_out;
     uint32_t* perm_out;
     uint32_t* overflow;
+    int shift;
     PSIM_HD void operator()(int64_t s) const
     {
         uint64_t k0 = key_in[s];
-        uint32_t hi = (uint32_t)(k0 >> 32);
-        if (s > 0 && (uint32_t)(key_in[s - 1] >> 32) == hi) return;
+        uint64_t hi = k0 >> shift;
+        if (s > 0 && (key_in[s - 1] >> shift) == hi) return;
         int64_t e = s + 1;
-        while (e < n && (uint32_t)(key_in[e] >> 32) == hi) ++e;
+        while (e < n && (key_in[e] >> shift) == hi) ++e;
         int64_t r = e - s;
         if (r == 1) {
             key_out[s] = k0;
@@ -295,58 +315,32 @@ PSIM_HD PSIM_FORCEINLINE uint32_t range_last(const uint64_t* key, uint32_t s, ui
     return lo;
 }
 
-// Writes the pre-order element array: for sorted particle s its owned internal
+// The pre-order element array holds, for sorted particle s, its owned internal
 // nodes (shallowest first) followed by its own leaf.  Internal node ids are
 // base[s] + k; the element of node id owned by s sits at index s + id.
-struct TreeEmit {
+// TreeEmitLeaves (one lane per particle) writes the leaf elements and, per owned node,
+// its first particle and depth; TreeEmitNodes (one lane per internal node) then finds
+// where each node's particle range ends and writes its element.
+struct TreeEmitLeaves {
     int64_t n;
-    const uint64_t* key;
     const int8_t* L;
     const uint32_t* owned;
     const uint32_t* base;      // exclusive scan of owned
     const vec2* spos;
     const double* smass;
-    uint32_t total_elems;      // n + number of internal nodes
     NodeRec* rec;
     uint32_t* node_first;
-    uint32_t* node_last;
     uint32_t* node_depth;      // u32 so it can be a radix-sort key
     uint32_t* node_id;
-    // The cell of depth d that starts at s ends just before the first t > s with L[t-1] < d,
-    // and deeper cells end no later than shallower ones: one forward scan over L closes the
-    // owned cells deepest first.  Most cells hold a handful of particles; after kScan steps
-    // the (few, large) cells still open are finished by a galloping search on the keys.
-    static constexpr int kScan = 24;
-    PSIM_HD void emit_node(int64_t s, uint32_t b, int lp, int d, uint32_t e) const
-    {
-        uint32_t id = b + (uint32_t)(d - lp - 1);
-        uint32_t skip = (e + 1 < (uint32_t)n) ? (e + 1) + base[e + 1] : total_elems;
-        NodeRec r;
-        r.mass = 0.0; r.x = 0.0; r.y = 0.0;
-        r.skip = skip;
-        r.depth = (uint32_t)d;
-        rec[(uint32_t)s + id] = r;
-        node_first[id] = (uint32_t)s;
-        node_last[id] = e;
-        node_depth[id] = (uint32_t)d;
-        node_id[id] = id;
-    }
     PSIM_HD void operator()(int64_t s) const
     {
         uint32_t b = base[s], own = owned[s];
         int lp = (s > 0) ? (int)L[s - 1] : -1;
-        if (own > 0) {
-            int d = lp + (int)own;              // deepest owned cell (= L[s]); ends at t >= s + 1
-            uint32_t t = (uint32_t)s;
-            for (int step = 0; step < kScan && d > lp; ++step) {
-                ++t;                            // L[n-1] = -1 closes every cell at the last particle
-                int m = (int)L[t];
-                while (d > lp && d > m) { emit_node(s, b, lp, d, t); --d; }
-            }
-            for (; d > lp; --d) {
-                t = range_last(key, (uint32_t)s, (uint32_t)n, d, t);
-                emit_node(s, b, lp, d, t);
-            }
+        for (uint32_t k = 0; k < own; ++k) {
+            uint32_t id = b + k;
+            node_first[id] = (uint32_t)s;
+            node_depth[id] = (uint32_t)(lp + 1 + (int)k);
+            node_id[id] = id;
         }
         uint32_t le = (uint32_t)s + b + own;
         NodeRec r;
@@ -356,6 +350,72 @@ struct TreeEmit {
         r.skip = le + 1;
         r.depth = kLeaf;
         rec[le] = r;
+    }
+};
+
+// The cell of depth d that starts at particle s holds s .. e where e is the first t >= s
+// with L[t] < d (L[t] = levels shared by particles t and t + 1; L[n-1] = -1).  Most cells
+// hold a handful of particles, so the next kScan values of L are fetched at once; a
+// larger cell is finished by a galloping search on the keys.
+constexpr uint32_t kDepthDone = 32;      // depth-sort key of a cell whose centre of mass is already final
+struct TreeEmitNodes {
+    static constexpr int kScan = 8;
+    int64_t count;             // internal nodes
+    int64_t n;
+    const uint64_t* key;
+    const int8_t* L;
+    const uint32_t* base;
+    const uint32_t* node_first;
+    uint32_t* node_depth;
+    const vec2* spos;
+    const double* smass;
+    uint32_t total_elems;      // n + number of internal nodes
+    NodeRec* rec;
+    uint32_t* node_last;
+    PSIM_HD void operator()(int64_t id) const
+    {
+        const uint32_t s = node_first[id];
+        const int d = (int)node_depth[id];
+        const uint32_t last = (uint32_t)n - 1;
+        int m[kScan];
+        for (int i = 0; i < kScan; ++i) {
+            uint32_t t = s + 1 + (uint32_t)i;       // L[s] >= d: the owner shares d levels with s + 1
+            m[i] = (int)L[t < last ? t : last];
+        }
+        uint32_t e = 0;
+        bool found = false;
+        for (int i = 0; i < kScan; ++i)
+            if (!found && m[i] < d) { e = s + 1 + (uint32_t)i; found = true; }
+        if (!found) e = range_last(key, s, (uint32_t)n, d, s + (uint32_t)kScan);
+        uint32_t skip = (e + 1 < (uint32_t)n) ? (e + 1) + base[e + 1] : total_elems;
+        NodeRec r;
+        r.mass = 0.0; r.x = 0.0; r.y = 0.0;
+        r.skip = skip;
+        r.depth = (uint32_t)d;
+        // A cell whose particles all part ways at the very next level (L = d between every
+        // neighbouring pair) has only leaves as children: its centre of mass is formed here, in
+        // the order and arithmetic of TreeCom, and the cell is filed under kDepthDone so that no
+        // per-depth pass visits it again.
+        if (found && d < kMaxInternalDepth && e - s <= 3u) {
+            bool all_leaves = (int)L[s] == d;
+            for (uint32_t i = 0; i + 1 < e - s; ++i) all_leaves = all_leaves && (m[i] == d);
+            if (all_leaves) {
+                double total = 0.0, nx = 0.0, ny = 0.0;
+                for (uint32_t t = s; t <= e; ++t) {
+                    double cm = smass[t];
+                    if (cm > 0) {
+                        total += cm;
+                        nx += spos[t].x * cm;
+                        ny += spos[t].y * cm;
+                    }
+                }
+                r.mass = total;
+                if (total > 0) { r.x = nx / total; r.y = ny / total; }
+                node_depth[id] = kDepthDone;
+            }
+        }
+        rec[s + (uint32_t)id] = r;
+        node_last[id] = e;
     }
 };
 

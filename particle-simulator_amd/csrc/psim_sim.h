@@ -239,13 +239,15 @@ public:
     }
 
     // small synchronous readback through the page-locked staging block
-    void readback(void* dst, const void* dev, size_t bytes)
+    void readback(void* dst, const void* dev, size_t bytes, bool check_fault = false)
     {
         if (bytes + 8 > kPinnedBytes) throw std::runtime_error("psim: internal: readback too large");
         be::copy_d2h(st, pinned, dev, bytes);
-        // every readback also fetches the word a scan / sort look-back sets if it gave up
+        // with check_fault the readback also fetches the word a scan / sort look-back sets if it
+        // gave up (asked for where the values read size the next launches: tree build, step end)
         uint32_t* fault = (uint32_t*)((char*)pinned + kPinnedBytes - 8);
-        be::copy_d2h(st, fault, be::lookback_fault_word(), 4);
+        *fault = 0;
+        if (check_fault) be::copy_d2h(st, fault, be::lookback_fault_word(), 4);
         be::sync(st);
         memcpy(dst, pinned, bytes);
         if (*fault != 0) throw std::runtime_error("psim: internal: scan / sort look-back timed out");
@@ -317,9 +319,18 @@ public:
         be::launch(s, n, d);
         be::exclusive_scan_u32(s, pcount.p, poffs.p, (uint64_t)n, scan_scratch.p, ctr);
         int64_t cwaves = (cells + 63) / 64;
-        tmp32.ensure((size_t)cwaves);
+        tmp32.ensure((size_t)cwaves + (size_t)(cwaves + 63) / 64 + 64);
         be::launch(s, cwaves * 64, WaveMaxOccupancy{cells, offsets.p, tmp32.p});
-        be::launch(s, 64, FinalMax{cwaves, tmp32.p, ctr + 2});
+        uint32_t* cur = tmp32.p;
+        uint32_t* nxt = tmp32.p + cwaves;
+        int64_t left = cwaves;
+        while (left > 4096) {
+            int64_t folded = (left + 63) / 64;
+            be::launch(s, folded * 64, WaveMaxU32{left, cur, nxt});
+            uint32_t* t = cur; cur = nxt; nxt = t;       // the folded list always fits where the longer one was
+            left = folded;
+        }
+        be::launch(s, 64, FinalMax{left, cur, ctr + 2});
     }
 
     // quadtree.py:177-196 (build) as sort + links + emit + bottom-up COM
@@ -341,9 +352,15 @@ public:
             if (attempt == 0) {
                 // radix passes on the high 32 bits, then FixRuns orders the (rare, short) runs
                 // of particles that share them
-                int half = be::radix_sort_pairs<uint64_t>(st, k, v, (uint64_t)n, 32, 64, sort_tmp.p);
+                // enough leading bits that a cell of that depth holds a quarter of a particle on
+                // average (whole 8-bit digits)
+                int lead = (ceil_log2_u64((uint64_t)n) + 2 + 7) / 8 * 8;
+                if (lead < 8) lead = 8;
+                if (lead > 64) lead = 64;
+                int half = be::radix_sort_pairs<uint64_t>(st, k, v, (uint64_t)n, 64 - lead, 64, sort_tmp.p);
                 be::dev_memset(st, counters.p + 4, 0, 4);
-                be::launch(st, n, FixRuns{n, key[half].p, perm[half].p, key[half ^ 1].p, perm[half ^ 1].p, counters.p + 4});
+                be::launch(st, n, FixRuns{n, key[half].p, perm[half].p, key[half ^ 1].p, perm[half ^ 1].p, counters.p + 4,
+                                          lead < 64 ? 64 - lead : 0});
                 sorted_key = half ^ 1;
             } else {
                 // a long run of near-coincident particles was left unsorted: full LSD sort
@@ -358,7 +375,7 @@ public:
             be::launch(st, n, TreeLinks{n, skey, L.p, owned.p});
             be::exclusive_scan_u32(st, owned.p, base.p, (uint64_t)n, scan_tmp.p, counters.p);
             uint32_t five[5];
-            readback(five, counters.p, 20);      // [0] internal nodes, [4] FixRuns overflow
+            readback(five, counters.p, 20, true);      // [0] internal nodes, [4] FixRuns overflow
             m = five[0];
             if (attempt == 0 && five[4] != 0) continue;
             break;
@@ -370,16 +387,23 @@ public:
         rec.ensure(c + mm);
         node_first.ensure(mm); node_last.ensure(mm); node_depth[0].ensure(mm); node_depth[1].ensure(mm);
         node_id[0].ensure(mm); node_id[1].ensure(mm); pe_node.ensure(mm);
-        TreeEmit e;
-        e.n = n; e.key = skey; e.L = L.p; e.owned = owned.p; e.base = base.p; e.spos = spos.p; e.smass = smass.p;
-        e.total_elems = (uint32_t)(n + m); e.rec = rec.p; e.node_first = node_first.p; e.node_last = node_last.p;
-        e.node_depth = node_depth[0].p; e.node_id = node_id[0].p;
+        TreeEmitLeaves e;
+        e.n = n; e.L = L.p; e.owned = owned.p; e.base = base.p; e.spos = spos.p; e.smass = smass.p; e.rec = rec.p;
+        e.node_first = node_first.p; e.node_depth = node_depth[0].p; e.node_id = node_id[0].p;
         be::launch(st, n, e);
+        if (m > 0) {
+            TreeEmitNodes en;
+            en.count = m; en.n = n; en.key = skey; en.L = L.p; en.base = base.p; en.node_first = node_first.p;
+            en.node_depth = node_depth[0].p; en.spos = spos.p; en.smass = smass.p; en.total_elems = (uint32_t)(n + m); en.rec = rec.p;
+            en.node_last = node_last.p;
+            be::launch(st, (int64_t)m, en);
+        }
         if (m > 0) {
             sort_tmp.ensure(be::sort_temp_words(mm));
             uint32_t* dk[2] = {node_depth[0].p, node_depth[1].p};
             uint32_t* dv[2] = {node_id[0].p, node_id[1].p};
             int sd = be::radix_sort_pairs<uint32_t>(st, dk, dv, (uint64_t)m, 0, 8, sort_tmp.p);
+            // segments 0..31: depths; segment 32 (kDepthDone): cells finished by TreeEmitNodes
             be::launch(st, (int64_t)m + 1, SegmentOffsets{(int64_t)m, node_depth[sd].p, depth_off.p, (uint32_t)(kKeyLevels + 1)});
             readback(depth_off_host, depth_off.p, sizeof(int32_t) * (kKeyLevels + 2));
             for (int d = kMaxInternalDepth; d >= 0; --d) {
@@ -786,6 +810,25 @@ public:
         be::sync(st);
     }
 
+    // Grid build and the first contact sweep's count pass on the side stream; released when
+    // the tree is built, so that it shares the device with the walk (FP64-bound) and not with
+    // the tree build (memory-bound like itself).  Joined by join_side_work().
+    bool side_running = false;
+    void start_side_work()
+    {
+        be::event_record(ev_drift, st);
+        be::stream_wait(st2, ev_drift);
+        build_grid(st2, sort_tmp2);
+        if (cfg.stage_mask & kStageCollisions) { detect_count(st2, scan_tmp2, counters2.p); predetected = true; }
+        be::event_record(ev_side, st2);
+        side_running = true;
+    }
+    void join_side_work()
+    {
+        if (side_running) be::stream_wait(st, ev_side);
+        side_running = false;
+    }
+
     // particle_system.py:518-563
     void step()
     {
@@ -802,20 +845,12 @@ public:
         timer.mark(st, 2);
         build_tree();
         timer.mark(st, 3);
-        if (side) {
-            // released when the tree is built, so that it shares the device with the walk (FP64-bound)
-            // and not with the tree build (memory-bound like itself)
-            be::event_record(ev_drift, st);
-            be::stream_wait(st2, ev_drift);
-            build_grid(st2, sort_tmp2);
-            if (cfg.stage_mask & kStageCollisions) { detect_count(st2, scan_tmp2, counters2.p); predetected = true; }
-            be::event_record(ev_side, st2);
-        }
+        if (side) start_side_work();
         gravity(acc2.p);
         timer.mark(st, 4);
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
-        if (side) be::stream_wait(st, ev_side);
+        join_side_work();
         timer.mark(st, 5);
         moved_valid = false;
         if (cfg.stage_mask & kStageCollisions) collisions();
@@ -840,10 +875,12 @@ public:
         timer.mark(st, 0);
         keys_and_drift(true);
         timer.mark(st, 1);
-        build_grid();
+        const bool side = cfg.overlap != 0 && n > 0;
+        if (!side) build_grid();
         timer.mark(st, 2);
         build_tree();
         timer.mark(st, 3);
+        if (side) start_side_work();
     }
     void stage_gravity(int64_t lo, int64_t hi, vec2* acc_sorted)
     {
@@ -856,6 +893,7 @@ public:
         be::launch(st, n, ScatterSorted{n, perm[sorted_key].p, acc_sorted, acc2.p});
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
+        join_side_work();
         timer.mark(st, 5);
         moved_valid = false;
         if (cfg.stage_mask & kStageCollisions) collisions();

@@ -294,11 +294,11 @@ class ParticleSystem:
         L = self.debug_array("L").astype(np.int64)
         rec = self.debug_array("rec")
         first = self.debug_array("node_first").astype(np.int64)
-        depth = self.debug_array("node_depth").astype(np.int64)
         n = len(key)
         m = len(first)
         ids = np.arange(m, dtype=np.int64)
         r = rec[first + ids] if m else rec[:0]
+        depth = r["depth"].astype(np.int64)
         shift = (64 - 2 * depth).astype(np.uint64)
         path = np.where(depth > 0, key[first] >> np.minimum(shift, np.uint64(63)), np.uint64(0)) if m else np.zeros(0, np.uint64)
         order = np.lexsort((path, depth)) if m else np.zeros(0, np.int64)
