@@ -708,13 +708,13 @@ __device__ __forceinline__ double mass_inv_r3(double m, double x)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// FOLD: theta^2 is a power of two, so w^2 < theta^2 d^2 is decided exactly as
-// (w^2 / theta^2) < d^2 and the caller passes w2_root already divided by theta^2.
+// FOLD: theta^2 is a power of two, w^2 < theta^2 d^2 is decided exactly as
+// (w^2 / theta^2) < d^2 and the elements' tags were built from W^2 / theta^2.
 template <bool COUNT, bool FOLD>
 __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
-    const double* __restrict__ inv_mass, vec2* __restrict__ acc_out, double w2_root, double theta2, double g_const,
+    const double* __restrict__ inv_mass, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,
     double softening, unsigned long long* __restrict__ counters)
 {
     // targets are the sorted particles [s_begin, s_end); results go to acc_out[particle
@@ -726,21 +726,19 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     uint32_t until = live ? 0u : 0xffffffffu;
     double ax = 0.0, ay = 0.0;
     uint32_t visits = 0, inter = 0, trips = 0, force_trips = 0;
-    // squared node width of depth d = w2_root * 4^-d: subtract 2d from the exponent field
-    const uint64_t w2_bits = (uint64_t)__double_as_longlong(w2_root);
     const double4_t* __restrict__ rec4 = reinterpret_cast<const double4_t*>(rec);
     uint32_t ju = 0;
     while (ju < total_elems) {
-        // one 32-byte scalar fetch per element: {mass, x, y, skip | depth << 32}
+        // one 32-byte scalar fetch per element: {mass, x, y, skip | tag << 32}
         const double4_t rv = rec4[ju];
-        const uint64_t meta = (uint64_t)__double_as_longlong(rv.w);
-        const uint32_t skip = (uint32_t)meta, depth = (uint32_t)(meta >> 32);
+        const uint32_t skip = (uint32_t)__double2loint(rv.w), tag = (uint32_t)__double2hiint(rv.w);
         const uint32_t ja = ju + 1u;
         const uint32_t jb = skip > ju ? skip : ja;           // strictly monotonic whatever the array holds
-        const bool leaf = depth == kLeaf;
+        const bool leaf = tag == kLeafTag;
         // internal: accept iff w^2 < theta^2 d^2 (which implies d^2 > 0 since w^2 > 0);
-        // leaf: interact iff 0 < d^2.  One compare serves both: lhs < scale * d^2.
-        const double lhs = leaf ? 0.0 : __longlong_as_double((long long)(w2_bits - ((uint64_t)(depth & 31u) << 53)));
+        // leaf: interact iff 0 < d^2.  One compare serves both: lhs < scale * d^2, with lhs
+        // assembled from the element's tag (high word) and the low word all depths share.
+        const double lhs = __hiloint2double((int)tag, (int)(leaf ? 0u : w2_lo));
         const bool active = until <= ju;
         const double dx = rv.y - px, dy = rv.z - py;
         const double d2 = fma(dx, dx, dy * dy);
@@ -786,28 +784,22 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     }
 }
 
-// theta^2 = 2^k exactly (theta = 0.5, the reference's default, gives 2^-2)?
-inline bool is_power_of_two(double v)
-{
-    int e = 0;
-    return v > 0.0 && frexp(v, &e) == 0.5 && e > -500 && e < 500;
-}
-
 template <bool COUNT>
 inline void launch_walk(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
                         const vec2* spos, const double* smass, const uint32_t* perm, const double* inv_mass, vec2* out,
-                        double w2_root, double theta2, double g_const, double softening, unsigned long long* counters)
+                        bool fold, uint32_t w2_lo, double theta2, double g_const, double softening,
+                        unsigned long long* counters)
 {
     if (hi <= lo) return;
     int64_t blocks = (hi - lo + 255) / 256;
     if (blocks > 0x7fffffffLL) throw std::runtime_error("launch_walk: grid too large");
-    if (is_power_of_two(theta2))
+    if (fold)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gravity_walk_wave_kernel<COUNT, true>), dim3((unsigned)blocks), dim3(256), 0,
-                           st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_root / theta2, theta2,
-                           g_const, softening, counters);
+                           st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_lo, theta2, g_const,
+                           softening, counters);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gravity_walk_wave_kernel<COUNT, false>), dim3((unsigned)blocks), dim3(256), 0,
-                           st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_root, theta2, g_const,
+                           st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_lo, theta2, g_const,
                            softening, counters);
     PSIM_HIP(hipGetLastError());
 }

@@ -28,7 +28,7 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     if (cfg.walk_mode == 0) {
         be::launch_walk<false>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
                                (const double*)smass.p, (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p,
-                               out, cfg.bounds_w * cfg.bounds_w, theta2, cfg.gravity_constant, cfg.softening,
+                               out, walk_fold, (uint32_t)w2_cmp_bits, theta2, cfg.gravity_constant, cfg.softening,
                                (unsigned long long*)nullptr);
         return;
     }
@@ -36,7 +36,7 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     GravityWalkSimple k;
     k.n = hi - lo; k.s0 = lo; k.sorted_out = sorted_out ? 1 : 0; k.rec = rec.p; k.total_elems = total; k.spos = spos.p;
     k.smass = smass.p; k.perm = perm[sorted_key].p; k.inv_mass = inv_mass.p; k.acc_out = out; k.w2tab = w2tab.p;
-    k.theta2 = theta2; k.g_const = cfg.gravity_constant; k.softening = cfg.softening; k.counters = nullptr;
+    k.root_tag = root_tag(); k.theta2 = theta2; k.g_const = cfg.gravity_constant; k.softening = cfg.softening; k.counters = nullptr;
     be::launch(st, hi - lo, k);
 }
 
@@ -269,8 +269,8 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     psim::be::launch_walk<true>(s->st, (int64_t)0, s->n, 0, (const psim::NodeRec*)s->rec.p, total,
                                 (const psim::vec2*)s->spos.p, (const double*)s->smass.p,
                                 (const uint32_t*)s->perm[s->sorted_key].p, (const double*)s->inv_mass.p, scratch.p,
-                                s->cfg.bounds_w * s->cfg.bounds_w, theta2, s->cfg.gravity_constant, s->cfg.softening,
-                                cnt.p);
+                                s->walk_fold, (uint32_t)s->w2_cmp_bits, theta2, s->cfg.gravity_constant,
+                                s->cfg.softening, cnt.p);
     unsigned long long h[32];
     psim::be::copy_d2h(s->st, h, cnt.p, 256);
     psim::be::sync(s->st);
@@ -285,7 +285,7 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     psim::GravityWalkSimple k;
     k.n = s->n; k.s0 = 0; k.sorted_out = 0; k.rec = s->rec.p; k.total_elems = total; k.spos = s->spos.p; k.smass = s->smass.p;
     k.perm = s->perm[s->sorted_key].p; k.inv_mass = s->inv_mass.p; k.acc_out = scratch.p; k.w2tab = s->w2tab.p;
-    k.theta2 = theta2; k.g_const = s->cfg.gravity_constant; k.softening = s->cfg.softening; k.counters = cnt.p;
+    k.root_tag = s->root_tag(); k.theta2 = theta2; k.g_const = s->cfg.gravity_constant; k.softening = s->cfg.softening; k.counters = cnt.p;
     psim::be::launch(s->st, s->n, k);
     out[0] = cnt.p[0];
     out[1] = cnt.p[1];

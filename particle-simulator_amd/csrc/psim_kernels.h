@@ -348,7 +348,7 @@ struct TreeEmitLeaves {
         r.x = spos[s].x;
         r.y = spos[s].y;
         r.skip = le + 1;
-        r.depth = kLeaf;
+        r.tag = kLeafTag;
         rec[le] = r;
     }
 };
@@ -370,6 +370,7 @@ struct TreeEmitNodes {
     const vec2* spos;
     const double* smass;
     uint32_t total_elems;      // n + number of internal nodes
+    uint32_t root_tag;         // NodeRec::tag of depth 0
     NodeRec* rec;
     uint32_t* node_last;
     PSIM_HD void operator()(int64_t id) const
@@ -391,7 +392,7 @@ struct TreeEmitNodes {
         NodeRec r;
         r.mass = 0.0; r.x = 0.0; r.y = 0.0;
         r.skip = skip;
-        r.depth = (uint32_t)d;
+        r.tag = node_tag(root_tag, d);
         // A cell whose particles all part ways at the very next level (L = d between every
         // neighbouring pair) has only leaves as children: its centre of mass is formed here, in
         // the order and arithmetic of TreeCom, and the cell is filed under kDepthDone so that no
@@ -531,10 +532,11 @@ struct TreePotential {
     NodeChildren ch;
     double* pe_node;
     double g_const, softening;
+    uint32_t root_tag;
     PSIM_HD void operator()(int64_t t) const
     {
         uint32_t id = (uint32_t)t;
-        int depth = (int)ch.rec[ch.node_first[id] + id].depth;
+        int depth = tag_depth(root_tag, ch.rec[ch.node_first[id] + id].tag);
         double cm[4], cx[4], cy[4];
         ch.load(id, depth, cm, cx, cy);
         double pe = 0.0;
@@ -576,6 +578,7 @@ struct GravityWalkSimple {
     const double* inv_mass;     // index space
     vec2* acc_out;              // index space
     const double* w2tab;        // [32] squared node width per depth
+    uint32_t root_tag;          // NodeRec::tag of depth 0
     double theta2, g_const, softening;
     uint32_t* counters;         // optional [2]: visits, interactions
     PSIM_HD void operator()(int64_t i) const
@@ -588,7 +591,7 @@ struct GravityWalkSimple {
             NodeRec r = rec[j];
             double dx = r.x - px, dy = r.y - py;
             double d2 = dx * dx + dy * dy;
-            double w2 = (r.depth == kLeaf) ? -1.0 : w2tab[r.depth];
+            double w2 = (r.tag == kLeafTag) ? -1.0 : w2tab[tag_depth(root_tag, r.tag)];
             ++visits;
             if (d2 > 0 && w2 < theta2 * d2) {
                 double f = r.mass * inv_cube_soft(d2 + softening);

@@ -100,6 +100,12 @@ public:
     DevBuf<int32_t> depth_off;
     DevBuf<double> w2tab;
     int32_t depth_off_host[40];
+    // What the walk compares squared distances with at the root: W^2 / theta^2 when theta^2 is a
+    // power of two (w^2 < theta^2 d^2 is then decided exactly as w^2 / theta^2 < d^2), else W^2.
+    // The high word is the root's NodeRec::tag, the low word is shared by all depths.
+    bool walk_fold = false;
+    uint64_t w2_cmp_bits = 0;
+    uint32_t root_tag() const { return (uint32_t)(w2_cmp_bits >> 32); }
 
     // grid
     DevBuf<uint32_t> ckey[2], cperm[2];
@@ -184,8 +190,19 @@ public:
         if (c.grid_w > kMaxGridDim || c.grid_h > kMaxGridDim) throw std::invalid_argument("psim: grid dimension above 65535 cells");
         if (!(c.bounds_w > 0) || !(c.bounds_h > 0)) throw std::invalid_argument("psim: bounds must be positive");
         bool geometry_changed = (c.grid_w != cfg.grid_w || c.grid_h != cfg.grid_h || c.cell_size != cfg.cell_size);
+        if (c.bounds_w != cfg.bounds_w || c.bounds_h != cfg.bounds_h || c.theta != cfg.theta) tree_valid = false;
         cfg = c;
         if (geometry_changed) tree_n = 0;
+        {
+            double theta2 = c.theta * c.theta;          // particle_system.py:88 theta * theta * dist_sq
+            int e = 0;
+            walk_fold = theta2 > 0.0 && frexp(theta2, &e) == 0.5 && e > -200 && e < 200;
+            double w2 = c.bounds_w * c.bounds_w;         // quadtree.py:25 root width, squared as in :88
+            double cmp = walk_fold ? w2 / theta2 : w2;   // exact: a power-of-two scaling
+            memcpy(&w2_cmp_bits, &cmp, 8);
+            // 31 levels must fit under the root's exponent (tag = root_tag - (depth << 21) stays positive)
+            if (!(cmp > 1e-250) || !(cmp < 1e250)) throw std::invalid_argument("psim: bounds / theta out of range");
+        }
         double w2[kKeyLevels];
         double w = c.bounds_w;
         for (int d = 0; d < kKeyLevels; ++d) { w2[d] = w * w; w = w / 2; }   // quadtree.py:25,132 width halves per level
@@ -394,7 +411,7 @@ public:
         if (m > 0) {
             TreeEmitNodes en;
             en.count = m; en.n = n; en.key = skey; en.L = L.p; en.base = base.p; en.node_first = node_first.p;
-            en.node_depth = node_depth[0].p; en.spos = spos.p; en.smass = smass.p; en.total_elems = (uint32_t)(n + m); en.rec = rec.p;
+            en.node_depth = node_depth[0].p; en.spos = spos.p; en.smass = smass.p; en.total_elems = (uint32_t)(n + m); en.rec = rec.p; en.root_tag = root_tag();
             en.node_last = node_last.p;
             be::launch(st, (int64_t)m, en);
         }
@@ -935,7 +952,7 @@ public:
         }
         if (tree_valid && n_internal > 0) {
             be::launch(st, (int64_t)n_internal, TreePotential{(int64_t)n_internal, node_children(), pe_node.p,
-                                                              cfg.gravity_constant, cfg.softening});
+                                                              cfg.gravity_constant, cfg.softening, root_tag()});
             be::reduce_sum_f64(st, pe_node.p, n_internal, red_tmp.p, red_out.p + 4);
         }
         else be::dev_memset(st, red_out.p + 4, 0, 8);

@@ -19,14 +19,22 @@ struct alignas(16) vec2 {
     double x, y;
 };
 
-// One element of the pre-order quadtree array: an internal node (depth 0..31)
-// or a particle leaf (depth == kLeaf).  skip = index of the first element after
-// this element's subtree.  32 bytes, so a wave-uniform fetch is one 32-B load.
+// One element of the pre-order quadtree array: an internal node or a particle
+// leaf.  skip = index of the first element after this element's subtree.  32 bytes,
+// so a wave-uniform fetch is one 32-B load.
+// tag: 0 for a leaf.  For an internal node of depth d it is the high word of the
+// FP64 number the walk compares squared distances with, root_tag - (d << 21):
+// halving the cell width per level divides its square by 4, i.e. subtracts 2 from
+// the exponent field, which starts at bit 20 of the high word (the low word is the
+// same for every depth and is kept by the walk).
 struct alignas(32) NodeRec {
     double mass, x, y;
     uint32_t skip;
-    uint32_t depth;
+    uint32_t tag;
 };
+constexpr uint32_t kLeafTag = 0;
+PSIM_HD PSIM_FORCEINLINE uint32_t node_tag(uint32_t root_tag, int depth) { return root_tag - ((uint32_t)depth << 21); }
+PSIM_HD PSIM_FORCEINLINE int tag_depth(uint32_t root_tag, uint32_t tag) { return (int)((root_tag - tag) >> 21); }
 
 // One particle in cell-sorted ("slot") order: everything a neighbour test needs
 // in a single 32-byte record (position, integer radius, particle index, cell).
@@ -38,7 +46,6 @@ struct alignas(32) CellBody {
     uint32_t cxy;      // cell column | cell row << 16
 };
 
-constexpr uint32_t kLeaf = 255;
 constexpr int kKeyLevels = 32;          // Morton key: 32 levels x 2 bits
 constexpr int kMaxInternalDepth = 31;   // children of depth-31 nodes are bucket leaves
 

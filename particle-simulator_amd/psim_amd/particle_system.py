@@ -268,7 +268,7 @@ class ParticleSystem:
     _DEBUG_DTYPES = {
         "key": (np.uint64, ()), "perm": (np.uint32, ()), "L": (np.int8, ()), "owned": (np.uint32, ()),
         "base": (np.uint32, ()), "rec": (np.dtype([("mass", "f8"), ("x", "f8"), ("y", "f8"),
-                                                   ("skip", "u4"), ("depth", "u4")]), ()),
+                                                   ("skip", "u4"), ("tag", "u4")]), ()),
         "node_first": (np.uint32, ()), "node_last": (np.uint32, ()), "node_depth": (np.uint32, ()),
         "depth_offsets": (np.int32, ()), "grid_offsets": (np.int32, ()), "grid_indices": (np.int32, ()),
         "cell_key": (np.uint32, ()), "contact_ij": (np.int32, (2,)), "contact_vals": (np.float64, (3,)),
@@ -298,7 +298,10 @@ class ParticleSystem:
         m = len(first)
         ids = np.arange(m, dtype=np.int64)
         r = rec[first + ids] if m else rec[:0]
-        depth = r["depth"].astype(np.int64)
+        # particle s owns the internal nodes of depths L[s-1]+1 .. L[s]; node ids run base[s] ..
+        base = self.debug_array("base").astype(np.int64)
+        lp_all = np.concatenate(([-1], L[:-1])) if n else L
+        depth = (lp_all[first] + 1 + (ids - base[first])) if m else np.zeros(0, np.int64)
         shift = (64 - 2 * depth).astype(np.uint64)
         path = np.where(depth > 0, key[first] >> np.minimum(shift, np.uint64(63)), np.uint64(0)) if m else np.zeros(0, np.uint64)
         order = np.lexsort((path, depth)) if m else np.zeros(0, np.int64)
