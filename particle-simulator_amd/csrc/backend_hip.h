@@ -730,7 +730,8 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     uint32_t ju = 0;
     while (ju < total_elems) {
         // one 32-byte scalar fetch per element: {mass, x, y, skip | tag << 32}
-        const double4_t rv = rec4[ju];
+        // (byte offset in 32 bits: the launcher checked that the array is below 4 GiB)
+        const double4_t rv = *reinterpret_cast<const double4_t*>(reinterpret_cast<const char*>(rec4) + (ju << 5));
         const uint32_t skip = (uint32_t)__double2loint(rv.w), tag = (uint32_t)__double2hiint(rv.w);
         const uint32_t ja = ju + 1u;
         const uint32_t jb = skip > ju ? skip : ja;           // strictly monotonic whatever the array holds
@@ -793,6 +794,7 @@ inline void launch_walk(Stream st, int64_t lo, int64_t hi, int sorted_out, const
     if (hi <= lo) return;
     int64_t blocks = (hi - lo + 255) / 256;
     if (blocks > 0x7fffffffLL) throw std::runtime_error("launch_walk: grid too large");
+    if ((uint64_t)total * sizeof(NodeRec) >= (1ull << 32)) throw std::runtime_error("launch_walk: tree above 4 GiB");
     if (fold)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gravity_walk_wave_kernel<COUNT, true>), dim3((unsigned)blocks), dim3(256), 0,
                            st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_lo, theta2, g_const,
