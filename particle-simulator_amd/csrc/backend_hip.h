@@ -710,7 +710,8 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // FOLD: theta^2 is a power of two, w^2 < theta^2 d^2 is decided exactly as
 // (w^2 / theta^2) < d^2 and the elements' tags were built from W^2 / theta^2.
-template <bool COUNT, bool FOLD>
+// WIDE: the element array is 4 GiB or larger, so element offsets need 64 bits.
+template <bool COUNT, bool FOLD, bool WIDE>
 __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
@@ -730,8 +731,9 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     uint32_t ju = 0;
     while (ju < total_elems) {
         // one 32-byte scalar fetch per element: {mass, x, y, skip | tag << 32}
-        // (byte offset in 32 bits: the launcher checked that the array is below 4 GiB)
-        const double4_t rv = *reinterpret_cast<const double4_t*>(reinterpret_cast<const char*>(rec4) + (ju << 5));
+        // (byte offset in 32 bits unless the array is 4 GiB or larger)
+        const double4_t rv = WIDE ? rec4[ju]
+                                  : *reinterpret_cast<const double4_t*>(reinterpret_cast<const char*>(rec4) + (ju << 5));
         const uint32_t skip = (uint32_t)__double2loint(rv.w), tag = (uint32_t)__double2hiint(rv.w);
         const uint32_t ja = ju + 1u;
         const uint32_t jb = skip > ju ? skip : ja;           // strictly monotonic whatever the array holds
@@ -794,15 +796,15 @@ inline void launch_walk(Stream st, int64_t lo, int64_t hi, int sorted_out, const
     if (hi <= lo) return;
     int64_t blocks = (hi - lo + 255) / 256;
     if (blocks > 0x7fffffffLL) throw std::runtime_error("launch_walk: grid too large");
-    if ((uint64_t)total * sizeof(NodeRec) >= (1ull << 32)) throw std::runtime_error("launch_walk: tree above 4 GiB");
-    if (fold)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gravity_walk_wave_kernel<COUNT, true>), dim3((unsigned)blocks), dim3(256), 0,
-                           st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_lo, theta2, g_const,
-                           softening, counters);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gravity_walk_wave_kernel<COUNT, false>), dim3((unsigned)blocks), dim3(256), 0,
-                           st, lo, hi, sorted_out, rec, total, spos, smass, perm, inv_mass, out, w2_lo, theta2, g_const,
-                           softening, counters);
+    const bool wide = (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
+                           perm, inv_mass, out, w2_lo, theta2, g_const, softening, counters);
+    };
+    if (fold && !wide) go(gravity_walk_wave_kernel<COUNT, true, false>);
+    else if (fold) go(gravity_walk_wave_kernel<COUNT, true, true>);
+    else if (!wide) go(gravity_walk_wave_kernel<COUNT, false, false>);
+    else go(gravity_walk_wave_kernel<COUNT, false, true>);
     PSIM_HIP(hipGetLastError());
 }
 

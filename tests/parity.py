@@ -154,3 +154,15 @@ def clustered_state(n, bounds, seed, clusters, per, spread):
             k += 1
     perm = rng.permutation(n)          # knots scattered through the index space
     return dict(positions=pos[perm], masses=masses[perm], temperatures=temps[perm])
+
+
+def gaussian_cluster_state(n, bounds, sigma, seed, temp_lo=0.3, temp_hi=0.9):
+    """one Gaussian blob about the centre (dense-core stress: many
+    particles per grid cell, long contact chains, many solver rounds)"""
+    rng = np.random.default_rng(seed)
+    b = np.array(bounds, dtype=np.float64)
+    pos = b / 2 + rng.normal(0.0, sigma, (n, 2))
+    out = ((pos < 5.0) | (pos > b - 5.0)).any(axis=1)
+    pos[out] = 5.0 + rng.random((int(out.sum()), 2)) * (b - 10.0)     # tails re-drawn uniformly (no coincident points)
+    return dict(positions=pos, masses=rng.uniform(5.0, 20.0, (n, 1)),
+                temperatures=rng.uniform(temp_lo, temp_hi, (n, 1)))

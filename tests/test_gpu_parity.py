@@ -89,6 +89,16 @@ def test_full_size_1Mi_disk_gravity_only_vs_oracle():
                               oracle_threads=_host_threads(), oracle_fast_pow=True)
 
 
+@pytest.mark.parametrize("n,sigma", [(100000, 1060.0), (30000, 250.0)])
+def test_dense_cluster_vs_oracle(n, sigma):
+    """a Gaussian blob: up to a few hundred particles per grid cell; the tighter one is a
+    single connected lump of contacts (tens of fixed-point iterations, a thousand
+    dependency rounds per step).  Two steps, contact pair lists bit-exact."""
+    bounds = (4000, 4000)
+    st = parity.gaussian_cluster_state(n, bounds, sigma, 3)
+    parity.run_against_oracle(n, SIM, 1, bounds, 2, HIP, state=st, oracle_threads=_host_threads())
+
+
 def test_oracle_dense_hot_20k():
     """4x default density, hot start: contact chains and explosions"""
     sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Robustness run at sizes far above the benchmark's: N particles at the reference's
+default density, a few full steps, stage times and counts printed (no oracle at this
+size; the invariants checked are the ones that do not need one)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "particle-simulator_amd")):
+    sys.path.insert(0, p)
+import numpy as np
+from bench import SIM
+from psim_amd.particle_system import ParticleSystem
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 26
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+side = float(np.sqrt(n / 1e-3))            # 1e-3 particles per square pixel, as config.json
+bounds = (side * np.sqrt(2.0), side / np.sqrt(2.0))
+t0 = time.time()
+ps = ParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds)
+print("init %.1f s" % (time.time() - t0), flush=True)
+m0 = float(ps.masses.sum())
+ps._calculate_gravity()
+e0 = ps.get_energies()
+for k in range(steps):
+    t = time.time()
+    ps.update()
+    c = ps.counts()
+    print("step %d: %.1f ms  %s" % (k, (time.time() - t) * 1e3, c), flush=True)
+    print("   stages", {a: round(b, 2) for a, b in ps.stage_times_ms().items()}, flush=True)
+    assert c["tree_nodes"] == 1 + 4 * c["internal_nodes"]
+e1 = ps.get_energies()
+print("energies before", e0, "after", e1)
+assert np.isfinite(e1).all()
+assert abs(float(ps.masses.sum()) - m0) <= 1e-9 * m0 or c["particles"] < n
+acc = ps.accelerations
+assert np.isfinite(acc).all() and np.isfinite(ps.positions).all()
+print("ok")
