@@ -179,7 +179,7 @@ def main():
             "config": {"workload": label, "particles": n, "theta": SIM["barnes_hut_theta"],
                        "multi_gpu": ("one simulation sharded over %d ranks: walk by sorted-target range, "
                                      "conduction by grid-slot range, RCCL all-gather" % world) if world > 1 else "single"},
-            "roofline": {"kernel": "gravity_walk_wave_kernel", "bound": "valu", "achieved": achieved,
+            "roofline": {"kernel": "gravity_walk_multi_kernel", "bound": "valu", "achieved": achieved,
                          "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": None,
                          "kernel_ms": walk_ms, "interactions_per_particle": inter / max(ps.num_particles, 1),

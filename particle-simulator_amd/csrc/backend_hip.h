@@ -708,6 +708,28 @@ __device__ __forceinline__ double mass_inv_r3(double m, double x)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// 32-byte scalar load whose issue point the compiler cannot move (it would otherwise sink
+// the second of two independent loads below the work on the first).  The result may only
+// be used after scalar_loads_wait() on it.
+__device__ __forceinline__ double4_t scalar_load32_issue(const double4_t* base, uint32_t byte_offset)
+{
+    double4_t r;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(r) : "s"(base), "s"(byte_offset));
+    return r;
+}
+__device__ __forceinline__ void scalar_loads_wait(double4_t& a, double4_t& b)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+}
+__device__ __forceinline__ void scalar_loads_wait(double4_t& a, double4_t& b, double4_t& c)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c));
+}
+__device__ __forceinline__ void scalar_loads_wait(double4_t& a, double4_t& b, double4_t& c, double4_t& d)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+}
+
 // FOLD: theta^2 is a power of two, w^2 < theta^2 d^2 is decided exactly as
 // (w^2 / theta^2) < d^2 and the elements' tags were built from W^2 / theta^2.
 // WIDE: the element array is 4 GiB or larger, so element offsets need 64 bits.
@@ -785,6 +807,121 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
             atomicAdd(&counters[3], (unsigned long long)force_trips);
         }
     }
+}
+
+// K walks per wave: each lane carries one particle of each of K groups of 64
+// Morton-adjacent particles (the wave covers 64 K consecutive sorted particles), each
+// group with its own cursor.  The K elements are requested together, so one wait covers
+// K fetches and one group's trip hides the others' latency; when the first group
+// finishes, the rest complete one after the other.
+template <int K, bool FOLD, bool WIDE>
+__global__ void __launch_bounds__(256) gravity_walk_multi_kernel(
+    int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
+    const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
+    const double* __restrict__ inv_mass, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,
+    double softening)
+{
+    static_assert(K >= 2 && K <= 4, "two to four walks per wave");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s0 = s_begin + ((int64_t)blockIdx.x * 4 + wave) * (64 * K) + lane;
+    double px[K], py[K], ax[K], ay[K];
+    uint32_t until[K], j[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int64_t s = s0 + 64 * k;
+        const bool live = s < s_end;
+        px[k] = 0.0; py[k] = 0.0; ax[k] = 0.0; ay[k] = 0.0;
+        if (live) { vec2 p = spos[s]; px[k] = p.x; py[k] = p.y; }
+        until[k] = live ? 0u : 0xffffffffu;
+        // a group that lies beyond the range altogether is not walked
+        j[k] = __builtin_amdgcn_ballot_w64(live) ? 0u : total_elems;
+    }
+    const double4_t* __restrict__ rec4 = reinterpret_cast<const double4_t*>(rec);
+    auto fetch = [&](uint32_t ju) -> double4_t {
+        return WIDE ? rec4[ju] : *reinterpret_cast<const double4_t*>(reinterpret_cast<const char*>(rec4) + (ju << 5));
+    };
+    // one trip of one group: the body of gravity_walk_wave_kernel's loop
+    auto trip = [&](const double4_t rv, uint32_t ju, double pxk, double pyk, double& axk, double& ayk,
+                    uint32_t& untilk) -> uint32_t {
+        const uint32_t skip = (uint32_t)__double2loint(rv.w), tag = (uint32_t)__double2hiint(rv.w);
+        const uint32_t ja = ju + 1u;
+        const uint32_t jb = skip > ju ? skip : ja;
+        const bool leaf = tag == kLeafTag;
+        const double lhs = __hiloint2double((int)tag, (int)(leaf ? 0u : w2_lo));
+        const bool active = untilk <= ju;
+        const double dx = rv.y - pxk, dy = rv.z - pyk;
+        const double d2 = fma(dx, dx, dy * dy);
+        bool accept;
+        if (FOLD) {
+            accept = lhs < d2;
+        } else {
+            const double scale = leaf ? 1.0 : theta2;
+            accept = lhs < scale * d2;
+        }
+        if (active && accept) {
+            double f = mass_inv_r3(rv.x, d2 + softening);
+            axk = fma(f, dx, axk);
+            ayk = fma(f, dy, ayk);
+            untilk = jb;
+        }
+        const bool descend = !leaf && (__builtin_amdgcn_ballot_w64(untilk <= ju) != 0ull);
+        return descend ? ja : jb;
+    };
+    if (!WIDE) {
+        // the kernel arguments the loop reads are pinned into registers here, so that the
+        // compiler places no scalar-load wait of its own between the requests and their use
+        asm volatile("" : "+s"(w2_lo), "+s"(theta2), "+s"(softening), "+s"(total_elems));
+        for (;;) {
+            bool all = true;
+#pragma unroll
+            for (int k = 0; k < K; ++k) all = all && (j[k] < total_elems);
+            if (!all) break;
+            double4_t rv[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) rv[k] = scalar_load32_issue(rec4, j[k] << 5);
+            if (K == 2) scalar_loads_wait(rv[0], rv[1]);
+            if (K == 3) scalar_loads_wait(rv[0], rv[1], rv[2]);
+            if (K == 4) scalar_loads_wait(rv[0], rv[1], rv[2], rv[K - 1]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) j[k] = trip(rv[k], j[k], px[k], py[k], ax[k], ay[k], until[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        while (j[k] < total_elems) j[k] = trip(fetch(j[k]), j[k], px[k], py[k], ax[k], ay[k], until[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int64_t s = s0 + 64 * k;
+        if (s < s_end) {
+            uint32_t p = perm[s];
+            double gm = g_const * smass[s];
+            double im = inv_mass[p];
+            vec2 a;
+            a.x = (gm * ax[k]) * im;
+            a.y = (gm * ay[k]) * im;
+            acc_out[sorted_out ? (uint32_t)s : p] = a;
+        }
+    }
+}
+
+template <int K>
+inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
+                              const vec2* spos, const double* smass, const uint32_t* perm, const double* inv_mass,
+                              vec2* out, bool fold, uint32_t w2_lo, double theta2, double g_const, double softening)
+{
+    if (hi <= lo) return;
+    int64_t blocks = (hi - lo + 256 * K - 1) / (256 * K);
+    if (blocks > 0x7fffffffLL) throw std::runtime_error("launch_walk_multi: grid too large");
+    const bool wide = (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
+                           perm, inv_mass, out, w2_lo, theta2, g_const, softening);
+    };
+    if (fold && !wide) go(gravity_walk_multi_kernel<K, true, false>);
+    else if (fold) go(gravity_walk_multi_kernel<K, true, true>);
+    else if (!wide) go(gravity_walk_multi_kernel<K, false, false>);
+    else go(gravity_walk_multi_kernel<K, false, true>);
+    PSIM_HIP(hipGetLastError());
 }
 
 template <bool COUNT>

@@ -26,6 +26,15 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     double theta2 = cfg.theta * cfg.theta;          // particle_system.py:88 theta * theta * dist_sq
 #if !defined(PSIM_HOSTLOOP)
     if (cfg.walk_mode == 0) {
+        // default: two walks per wave
+        be::launch_walk_multi<2>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
+                                 (const double*)smass.p, (const uint32_t*)perm[sorted_key].p,
+                                 (const double*)inv_mass.p, out, walk_fold, (uint32_t)w2_cmp_bits, theta2,
+                                 cfg.gravity_constant, cfg.softening);
+        return;
+    }
+    if (cfg.walk_mode == 2) {
+        // one walk per wave (the kernel the visit / interaction counts are taken with)
         be::launch_walk<false>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
                                (const double*)smass.p, (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p,
                                out, walk_fold, (uint32_t)w2_cmp_bits, theta2, cfg.gravity_constant, cfg.softening,

@@ -18,7 +18,7 @@ struct Config {
     double heat_coeff, restitution, pos_correct, explosion_eff, damping, explode_temp;
     int32_t cell_size, grid_w, grid_h, solver_iterations;
     int32_t stage_mask;
-    int32_t walk_mode;      // 0: wave-cooperative walk, 1: one lane per particle
+    int32_t walk_mode;      // 0: wave-cooperative walk, two groups per wave; 1: one lane per particle; 2: one group per wave
     int32_t debug;          // keep per-step debug arrays (contact log, delta temps)
     int32_t overlap;        // 1: grid build + first contact count pass on a side stream under the walk
 };

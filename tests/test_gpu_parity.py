@@ -29,7 +29,7 @@ def test_device_primitives(n):
     assert rc == 0, L.psim_last_error().decode()
 
 
-@pytest.mark.parametrize("walk_mode", [0, 1])
+@pytest.mark.parametrize("walk_mode", [0, 1, 2])
 @pytest.mark.parametrize("name", ["tiny64", "dense256", "dense400", "hot300", "fast200"])
 def test_golden_stepwise(name, walk_mode):
     parity.run_golden_stepwise(name, HIP, walk_mode=walk_mode)
@@ -48,7 +48,7 @@ def test_default_run_100_steps():
 
 def test_tree_gravity_20k():
     g = load_golden("tree20k")
-    for walk_mode in (0, 1):
+    for walk_mode in (0, 1, 2):
         s = parity.make_system(g, HIP, walk_mode=walk_mode)
         s._calculate_gravity()
         parity.check_tree(s, g, "init_")
