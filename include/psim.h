@@ -152,6 +152,17 @@ int psim_walk_counts(psim_context* ctx, int64_t out[4]);
  * device time of the kernel; it performs 20 n (n-1) flops by the walk's accounting. */
 int psim_brute_force_gravity(psim_context* ctx, double* accelerations_out, double* kernel_ms);
 
+/* draw() feed, replaces the per-particle Python of particle_system.py:587-624 up to the
+ * rasteriser call: xy_out host (n,2) int32 = int(position), rgba_out host (n,4) uint8 =
+ * colour of the temperature through the keyframe ramp (constants.py:37-45,
+ * particle_system.py:565-585), alpha 255.  12 bytes per particle cross PCIe instead of 80. */
+int psim_render_feed(psim_context* ctx, int32_t* xy_out, uint8_t* rgba_out);
+
+/* diagnostic (no counterpart in the reference, whose potential energy pairs sibling cells
+ * only, particle_system.py:27-67): exact softened pairwise potential energy
+ * -G sum_{i<j} m_i m_j / sqrt(d_ij^2 + s) of the current state, O(n^2) FP64. */
+int psim_pair_potential_energy(psim_context* ctx, double* out);
+
 /* parity hooks: copy a named internal device array to the host.
  * psim_debug_size returns the element count (or < 0 for an unknown name);
  * psim_debug_fetch copies min(bytes, size) bytes.  Names: key perm L owned base

@@ -356,6 +356,46 @@ int psim_brute_force_gravity(psim_context* ctx, double* accelerations_out, doubl
     PSIM_TRY(ctx && accelerations_out, brute_force_impl(ctx, accelerations_out, kernel_ms))
 }
 
+static void render_feed_impl(psim_context* ctx, int32_t* xy, uint8_t* rgba)
+{
+    use_device(ctx->device);
+    psim::Sim* s = ctx->sim;
+    if (s->n == 0) return;
+    psim::DevBuf<int32_t> dxy;
+    psim::DevBuf<uint8_t> drgba;
+    dxy.ensure(2 * (size_t)s->n);
+    drgba.ensure(4 * (size_t)s->n);
+    psim::be::launch(s->st, s->n, psim::RenderFeed{s->n, s->pos.p, s->temp.p, dxy.p, drgba.p, 0.0, s->cfg.explode_temp});
+    psim::be::copy_d2h(s->st, xy, dxy.p, (size_t)s->n * 8);
+    psim::be::copy_d2h(s->st, rgba, drgba.p, (size_t)s->n * 4);
+    psim::be::sync(s->st);
+}
+
+int psim_render_feed(psim_context* ctx, int32_t* xy_out, uint8_t* rgba_out)
+{
+    PSIM_TRY(ctx && xy_out && rgba_out, render_feed_impl(ctx, xy_out, rgba_out))
+}
+
+static void pair_potential_impl(psim_context* ctx, double* out)
+{
+    use_device(ctx->device);
+    psim::Sim* s = ctx->sim;
+    *out = 0.0;
+    if (s->n == 0) return;
+    psim::DevBuf<double> rows;
+    rows.ensure((size_t)s->n);
+    psim::be::launch(s->st, s->n, psim::PairPotentialRow{s->n, s->pos.p, s->mass.p, s->cfg.softening, rows.p});
+    psim::be::reduce_sum_f64(s->st, rows.p, (uint64_t)s->n, s->red_tmp.p, s->red_out.p + 5);
+    double sum = 0.0;
+    s->readback(&sum, s->red_out.p + 5, 8);
+    *out = -0.5 * s->cfg.gravity_constant * sum;
+}
+
+int psim_pair_potential_energy(psim_context* ctx, double* out)
+{
+    PSIM_TRY(ctx && out, pair_potential_impl(ctx, out))
+}
+
 int psim_stage_times(psim_context* ctx, double out_ms[8])
 {
     PSIM_TRY(ctx && out_ms, {

@@ -1575,6 +1575,66 @@ struct EnergyTerms {
     }
 };
 
+// What the reference's draw() computes per particle before it calls the rasteriser
+// (particle_system.py:587-624): int-truncated coordinates and the colour of the
+// temperature through the keyframe ramp (constants.py:37-45, particle_system.py:565-585:
+// first segment with pos1 <= t <= pos2, channels c1 (1 - u) + c2 u truncated to int).
+// 12 bytes per particle leave the device instead of the 80 of the full state.
+struct RenderFeed {
+    int64_t n;
+    const vec2* pos;
+    const double* temp;
+    int32_t* xy;               // (n, 2)
+    uint8_t* rgba;             // (n, 4), alpha 255
+    double t_min, t_max;       // constants.py:33-34
+    PSIM_HD void operator()(int64_t i) const
+    {
+        const double kpos[7] = {0.0, 0.1, 0.25, 0.4, 0.55, 0.7, 1.0};
+        const double kcol[7][3] = {{0, 0, 0}, {75, 0, 130}, {0, 0, 255}, {0, 255, 0}, {255, 255, 0}, {255, 0, 0},
+                                   {255, 255, 255}};
+        double T = temp[i];
+        // np.nan_to_num(nan=min, posinf=max, neginf=min), then clip((T - min) / (max - min), 0, 1)
+        if (T != T) T = t_min;
+        double t = (T - t_min) / (t_max - t_min);
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        int r = 255, g = 255, b = 255;
+        for (int k = 0; k < 6; ++k) {
+            if (kpos[k] <= t && t <= kpos[k + 1]) {
+                double u = (t - kpos[k]) / (kpos[k + 1] - kpos[k]);
+                r = (int)(kcol[k][0] * (1 - u) + kcol[k + 1][0] * u);
+                g = (int)(kcol[k][1] * (1 - u) + kcol[k + 1][1] * u);
+                b = (int)(kcol[k][2] * (1 - u) + kcol[k + 1][2] * u);
+                break;
+            }
+        }
+        vec2 p = pos[i];
+        xy[2 * i] = (int32_t)p.x;          // int(): truncation toward zero
+        xy[2 * i + 1] = (int32_t)p.y;
+        rgba[4 * i] = (uint8_t)r; rgba[4 * i + 1] = (uint8_t)g; rgba[4 * i + 2] = (uint8_t)b; rgba[4 * i + 3] = 255;
+    }
+};
+
+// one term of the exact pairwise potential: phi_i = sum_j m_j / sqrt(d_ij^2 + s) over d_ij^2 > 0
+// (the all-pairs counterpart of particle_system.py:43-63, which only pairs sibling cells)
+struct PairPotentialRow {
+    int64_t n;
+    const vec2* pos;
+    const double* mass;
+    double softening;
+    double* out;               // m_i phi_i
+    PSIM_HD void operator()(int64_t i) const
+    {
+        vec2 p = pos[i];
+        double phi = 0.0;
+        for (int64_t j = 0; j < n; ++j) {
+            double dx = pos[j].x - p.x, dy = pos[j].y - p.y;
+            double d2 = dx * dx + dy * dy;
+            if (d2 > 0) phi += mass[j] / sqrt(d2 + softening);
+        }
+        out[i] = mass[i] * phi;
+    }
+};
+
 struct FillI32 {
     int64_t n;
     int32_t* p;

@@ -25,7 +25,7 @@ EXPORTS = [
     "psim_debug_size", "psim_debug_fetch", "psim_selftest", "psim_stage_times",
     "psim_last_error", "psim_version",
     "psim_stage_build", "psim_stage_gravity", "psim_stage_kick_collide", "psim_stage_conduction",
-    "psim_stage_finish", "psim_brute_force_gravity",
+    "psim_stage_finish", "psim_brute_force_gravity", "psim_render_feed", "psim_pair_potential_energy",
 ]
 
 
@@ -98,6 +98,8 @@ def load(path=None):
     L.psim_stage_conduction.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.psim_stage_finish.argtypes = [vp, vp]
     L.psim_brute_force_gravity.argtypes = [vp, vp, c_dp]
+    L.psim_render_feed.argtypes = [vp, vp, vp]
+    L.psim_pair_potential_energy.argtypes = [vp, c_dp]
     L.psim_last_error.restype = ctypes.c_char_p
     L.psim_version.restype = ctypes.c_char_p
     for name in EXPORTS:

@@ -259,6 +259,24 @@ class ParticleSystem:
             self._ctx, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ms)))
         return out, ms.value
 
+    def render_feed(self):
+        """What draw() needs, computed on the device (particle_system.py:587-624 up to the
+        rasteriser call): (xy int32 (n,2) = int(position), rgba uint8 (n,4))."""
+        n = self.num_particles
+        xy = np.empty((n, 2), dtype=np.int32)
+        rgba = np.empty((n, 4), dtype=np.uint8)
+        if n:
+            _capi.check(self._lib, self._lib.psim_render_feed(
+                self._ctx, xy.ctypes.data_as(ctypes.c_void_p), rgba.ctypes.data_as(ctypes.c_void_p)))
+        return xy, rgba
+
+    def exact_potential_energy(self):
+        """-G sum_{i<j} m_i m_j / sqrt(d^2 + s) over all pairs (O(n^2) diagnostic; the
+        reference's own potential energy pairs sibling cells only)."""
+        out = ctypes.c_double(0.0)
+        _capi.check(self._lib, self._lib.psim_pair_potential_energy(self._ctx, ctypes.byref(out)))
+        return out.value
+
     def stage_times_ms(self):
         out = (ctypes.c_double * 8)()
         _capi.check(self._lib, self._lib.psim_stage_times(self._ctx, out))
@@ -323,16 +341,13 @@ class ParticleSystem:
         """particle_system.py:587-624: one filled circle per particle, coloured by
         temperature through the keyframe ramp of constants.py:37-45."""
         import pygame
-        pos, temps, radii = self.positions, self.temperatures, self.radii
-        sane = np.nan_to_num(temps[:, 0], nan=constants.COLOR_MIN_TEMP, posinf=constants.COLOR_MAX_TEMP,
-                             neginf=constants.COLOR_MIN_TEMP)
-        t = np.clip((sane - constants.COLOR_MIN_TEMP) / (constants.COLOR_MAX_TEMP - constants.COLOR_MIN_TEMP), 0, 1)
-        rgb = constants.ramp_colors(t)
+        xy, rgba = self.render_feed()
+        radii = self.radii
         for i in range(self.num_particles):
-            c = (int(rgb[i, 0]), int(rgb[i, 1]), int(rgb[i, 2]))
+            c = (int(rgba[i, 0]), int(rgba[i, 1]), int(rgba[i, 2]))
             if is_glow_pass:
                 c = c + (255,)
-            pygame.draw.circle(screen, c, (int(pos[i, 0]), int(pos[i, 1])), int(radii[i, 0]))
+            pygame.draw.circle(screen, c, (int(xy[i, 0]), int(xy[i, 1])), int(radii[i, 0]))
 
 
 def _make_property(name):

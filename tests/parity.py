@@ -166,3 +166,46 @@ def gaussian_cluster_state(n, bounds, sigma, seed, temp_lo=0.3, temp_hi=0.9):
     pos[out] = 5.0 + rng.random((int(out.sum()), 2)) * (b - 10.0)     # tails re-drawn uniformly (no coincident points)
     return dict(positions=pos, masses=rng.uniform(5.0, 20.0, (n, 1)),
                 temperatures=rng.uniform(temp_lo, temp_hi, (n, 1)))
+
+
+def check_render_feed_and_pair_potential(library):
+    """device-side draw() feed against the reference's per-particle expressions
+    (particle_system.py:565-624), and the exact pairwise potential energy against NumPy"""
+    from psim_amd import constants
+    n, bounds = 700, (400.0, 300.0)
+    rng = np.random.default_rng(11)
+    temps = rng.uniform(-0.2, 1.3, (n, 1))
+    temps[:5, 0] = [np.nan, np.inf, -np.inf, 0.0, 1.0]
+    temps[5:12, 0] = [0.1, 0.25, 0.4, 0.55, 0.7, 0.0999999999, 0.7000000001]     # keyframe boundaries
+    st = dict(positions=rng.random((n, 2)) * np.array(bounds), masses=rng.uniform(5, 20, (n, 1)), temperatures=temps)
+    sim = dict(particle_count=n, min_mass=5.0, max_mass=20.0, gravity_constant=0.01, softening_factor=10,
+               barnes_hut_theta=0.5, min_temp=0.05, max_temp=0.1, heat_transfer_coefficient=0.1,
+               coefficient_of_restitution=0.5, grid_cell_size_multiplier=10.0, position_correction_factor=1.05,
+               collision_solver_iterations=1, explosion_efficiency=0.5, thermal_damping_factor=0.0005)
+    s = ParticleSystem(n, sim, rng, bounds, library=library, state=st)
+    xy, rgba = s.render_feed()
+    np.testing.assert_array_equal(xy, st["positions"].astype(np.int64))        # int(): toward zero
+    sane = np.nan_to_num(temps[:, 0], nan=constants.COLOR_MIN_TEMP, posinf=constants.COLOR_MAX_TEMP,
+                         neginf=constants.COLOR_MIN_TEMP)
+    t = np.clip((sane - constants.COLOR_MIN_TEMP) / (constants.COLOR_MAX_TEMP - constants.COLOR_MIN_TEMP), 0, 1)
+    want = np.zeros((n, 3), dtype=np.int64)
+    keys = constants.COLOR_GRADIENT_KEYFRAMES
+    for i in range(n):                      # the reference's own loop, particle_system.py:570-585
+        col = keys[-1][1]
+        for k in range(len(keys) - 1):
+            p1, c1 = keys[k]
+            p2, c2 = keys[k + 1]
+            if p1 <= t[i] <= p2:
+                u = (t[i] - p1) / (p2 - p1)
+                col = tuple(int(c1[c] * (1 - u) + c2[c] * u) for c in range(3))
+                break
+        want[i] = col
+    np.testing.assert_array_equal(rgba[:, :3], want)
+    assert (rgba[:, 3] == 255).all()
+    pos, m = st["positions"], st["masses"][:, 0]
+    d = pos[:, None, :] - pos[None, :, :]
+    d2 = (d ** 2).sum(-1)
+    iu = np.triu_indices(n, 1)
+    pe = -(0.01 * m[iu[0]] * m[iu[1]] / np.sqrt(d2[iu] + 10)).sum()
+    np.testing.assert_allclose(s.exact_potential_energy(), pe, rtol=1e-12)
+    s.close()

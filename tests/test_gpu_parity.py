@@ -159,3 +159,7 @@ def test_tree_walk_against_all_pairs():
         scale = np.abs(brute).max()
         assert np.abs(s.accelerations - brute).max() <= tol * scale, theta
         assert ms > 0
+
+
+def test_render_feed_and_pair_potential():
+    parity.check_render_feed_and_pair_potential(HIP)

@@ -119,3 +119,8 @@ def test_headless_runner_logs_like_main(tmp_path, monkeypatch):
                 "AccumulatedPE_Gain=", "AccumulatedHeat="):
         assert key in lines[1]
     assert "particle-updates/s" in log and "momentum=" in log
+
+
+def test_render_feed_and_pair_potential_hostloop():
+    import parity
+    parity.check_render_feed_and_pair_potential(HOSTLOOP)
