@@ -38,13 +38,20 @@ def setup_logging(config, log_root="runs"):
     logger.info(f"Logging initialized. Run ID: {run_id}. Log file: {log_file}")
 
 
-def run(config, ticks, bounds=(constants.WIDTH, constants.HEIGHT), device=0, log_every=100):
+def run(config, ticks, bounds=(constants.WIDTH, constants.HEIGHT), device=0, log_every=100, library=None,
+        restore=None, save=None):
+    """restore / save: .npz checkpoint paths (no counterpart in the reference).  A restored
+    run carries its accelerations, so it is not primed again."""
     sim_config = config['simulation']
-    rng = np.random.default_rng(config['master_seed'])
-    logger.info(f"Master RNG initialized with seed: {config['master_seed']}")
-    system = ParticleSystem(num_particles=sim_config['particle_count'], config=sim_config, rng=rng,
-                            bounds=bounds, device=device)
-    system._calculate_gravity()          # main.py:151
+    if restore:
+        system = ParticleSystem.from_checkpoint(restore, device=device, library=library)
+        logger.info(f"Restored {system.num_particles} particles from {restore}")
+    else:
+        rng = np.random.default_rng(config['master_seed'])
+        logger.info(f"Master RNG initialized with seed: {config['master_seed']}")
+        system = ParticleSystem(num_particles=sim_config['particle_count'], config=sim_config, rng=rng,
+                                bounds=bounds, device=device, library=library)
+        system._calculate_gravity()          # main.py:151
     accumulated = [0.0, 0.0, 0.0]
     last_logged_energy = 0.0
     first_log = True
@@ -75,6 +82,9 @@ def run(config, ticks, bounds=(constants.WIDTH, constants.HEIGHT), device=0, log
     px, py = system.get_total_momentum()
     logger.info(f"{ticks} ticks in {dt:.3f} s: {updates / dt:.4g} particle-updates/s; "
                 f"momentum=({px:+.6g}, {py:+.6g}); particles={system.num_particles}")
+    if save:
+        system.save_checkpoint(save)
+        logger.info(f"Checkpoint written to {save}")
     return system
 
 
@@ -84,13 +94,15 @@ def main():
     ap.add_argument("--ticks", type=int, default=1000)
     ap.add_argument("--bounds", type=float, nargs=2, default=[constants.WIDTH, constants.HEIGHT])
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--restore", default=None, help=".npz checkpoint to continue from")
+    ap.add_argument("--save", default=None, help="write a .npz checkpoint after the last tick")
     args = ap.parse_args()
     with open(args.config, 'r') as f:
         config = json.load(f)
     setup_logging(config)
     logger.info("Application starting...")
     logger.info(f"Loaded configuration: {config}")
-    run(config, args.ticks, tuple(args.bounds), args.device)
+    run(config, args.ticks, tuple(args.bounds), args.device, restore=args.restore, save=args.save)
     logger.info("Application shutting down.")
 
 

@@ -165,6 +165,33 @@ class ParticleSystem:
             self._ptr("masses"), self._ptr("inverse_masses"), self._ptr("temperatures"), self._ptr("radii")))
         self._stale = False
 
+    # ------------------------------------------------------------------ checkpoint (the reference has none)
+    def save_checkpoint(self, path):
+        """Full state + configuration as one .npz: a run restored from it continues
+        bit-identically (the step holds no other state between calls)."""
+        import json
+        self._refresh()
+        h = self._host
+        np.savez(path, positions=h["positions"], velocities=h["velocities"], accelerations=h["accelerations"],
+                 masses=h["masses"], temperatures=h["temperatures"], bounds=np.asarray(self.bounds, dtype=np.float64),
+                 config=np.array(json.dumps(self.config)),
+                 collision_totals=np.array([self.pe_gain_collisions, self.ke_loss_collisions,
+                                            self.heat_generated_collisions]))
+
+    @classmethod
+    def from_checkpoint(cls, path, **kwargs):
+        import json
+        z = np.load(path, allow_pickle=False)
+        config = json.loads(str(z["config"]))
+        n = z["positions"].shape[0]
+        bounds = tuple(float(b) for b in z["bounds"])
+        if all(b == int(b) for b in bounds):
+            bounds = tuple(int(b) for b in bounds)
+        state = {k: z[k] for k in ("positions", "velocities", "accelerations", "masses", "temperatures")}
+        ps = cls(n, config, None, bounds, state=state, **kwargs)
+        ps.pe_gain_collisions, ps.ke_loss_collisions, ps.heat_generated_collisions = (float(v) for v in z["collision_totals"])
+        return ps
+
     def close(self):
         if getattr(self, "_ctx", None):
             self._lib.psim_destroy(self._ctx)

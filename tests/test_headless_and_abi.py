@@ -97,20 +97,11 @@ def test_config_is_reread_each_step():
 
 def test_headless_runner_logs_like_main(tmp_path, monkeypatch):
     from psim_amd import headless
-    import psim_amd.particle_system as ps_mod
     monkeypatch.chdir(tmp_path)
     config = json.load(open(os.path.join(ROOT, "particle-simulator_amd", "config.json")))
     config["simulation"]["particle_count"] = 400
     headless.setup_logging(config)
-    orig = ps_mod.ParticleSystem.__init__
-
-    def patched(self, *a, **k):
-        k.setdefault("library", HOSTLOOP)
-        k.setdefault("walk_mode", 1)
-        orig(self, *a, **k)
-
-    monkeypatch.setattr(ps_mod.ParticleSystem, "__init__", patched)
-    system = headless.run(config, ticks=101, bounds=(800, 400))
+    system = headless.run(config, ticks=101, bounds=(800, 400), library=HOSTLOOP)
     assert system.num_particles == 400
     log = open(tmp_path / "runs" / "sim_run_001" / "simulation.log").read()
     lines = [l for l in log.splitlines() if "Tick=" in l]
@@ -124,3 +115,23 @@ def test_headless_runner_logs_like_main(tmp_path, monkeypatch):
 def test_render_feed_and_pair_potential_hostloop():
     import parity
     parity.check_render_feed_and_pair_potential(HOSTLOOP)
+
+
+def test_checkpoint_restore_continues_bit_identically(tmp_path):
+    """6 steps in one go == 3 steps, checkpoint, restore into a new system, 3 steps"""
+    sim = dict(SIM, particle_count=300, min_temp=0.5, max_temp=0.99)
+    bounds = (300, 200)
+    a = ParticleSystem(300, dict(sim), np.random.default_rng(8), bounds, library=HOSTLOOP)
+    a._calculate_gravity()
+    a.update(6)
+    b = ParticleSystem(300, dict(sim), np.random.default_rng(8), bounds, library=HOSTLOOP)
+    b._calculate_gravity()
+    b.update(3)
+    path = str(tmp_path / "ckpt.npz")
+    b.save_checkpoint(path)
+    b.close()
+    c = ParticleSystem.from_checkpoint(path, library=HOSTLOOP)
+    c.update(3)
+    assert c.num_particles == a.num_particles
+    for name in ("positions", "velocities", "accelerations", "temperatures", "masses", "radii"):
+        np.testing.assert_array_equal(getattr(c, name), getattr(a, name), err_msg=name)
