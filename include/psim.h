@@ -112,6 +112,11 @@ int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* ac
 int psim_stage_kick_collide(psim_context* ctx, const double* acc_sorted);
 int psim_stage_conduction(psim_context* ctx, int64_t k_lo, int64_t k_hi, double* temp_slots);
 int psim_stage_finish(psim_context* ctx, const double* temp_slots);
+/* after psim_stage_kick_collide: *out = 1 when this step's conduction needs the exchange of
+ * temp_slots (full sweep split by slot range), 0 when every rank does all of it locally
+ * (sweep around the slots the contacts touched) and the all-gather can be skipped.  The
+ * answer depends on the state only, so it is the same on every rank. */
+int psim_stage_conduction_exchanges(psim_context* ctx, int32_t* out);
 
 /* replaces: get_total_kinetic_energy / get_total_potential_energy /
  * get_total_thermal_energy (particle_system.py:765-804); out[0..2] = KE, PE, TE,

@@ -210,6 +210,15 @@ int psim_stage_conduction(psim_context* ctx, int64_t k_lo, int64_t k_hi, double*
     })
 }
 
+int psim_stage_conduction_exchanges(psim_context* ctx, int32_t* out)
+{
+    PSIM_TRY(ctx && out, {
+        psim::Sim* s = ctx->sim;
+        bool cond = (s->cfg.stage_mask & psim::kStageConduction) != 0;
+        *out = (cond && s->n > 0 && !s->sparse_conduction_possible()) ? 1 : 0;
+    })
+}
+
 int psim_stage_finish(psim_context* ctx, const double* temp_slots)
 {
     PSIM_TRY(ctx && temp_slots, {

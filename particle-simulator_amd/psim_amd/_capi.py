@@ -26,6 +26,7 @@ EXPORTS = [
     "psim_last_error", "psim_version",
     "psim_stage_build", "psim_stage_gravity", "psim_stage_kick_collide", "psim_stage_conduction",
     "psim_stage_finish", "psim_brute_force_gravity", "psim_render_feed", "psim_pair_potential_energy",
+    "psim_stage_conduction_exchanges",
 ]
 
 
@@ -97,6 +98,7 @@ def load(path=None):
     L.psim_stage_kick_collide.argtypes = [vp, vp]
     L.psim_stage_conduction.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.psim_stage_finish.argtypes = [vp, vp]
+    L.psim_stage_conduction_exchanges.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.psim_brute_force_gravity.argtypes = [vp, vp, c_dp]
     L.psim_render_feed.argtypes = [vp, vp, vp]
     L.psim_pair_potential_energy.argtypes = [vp, c_dp]

@@ -9,9 +9,11 @@ dominate the step are split by range and their outputs exchanged:
   * gravity: rank r walks the tree for a contiguous range of Morton-sorted
     target particles; accelerations are all-gathered in sorted order (16 B per
     particle) -- one all-gather per step;
-  * conduction + cooling: rank r sweeps a contiguous range of grid slots (whole
-    runs of row-major cells, i.e. a spatial slab); temperatures are all-gathered
-    in slot order (8 B per particle) -- one all-gather per step.
+  * conduction + cooling: when the step needs the full neighbour sweep, rank r
+    sweeps a contiguous range of grid slots (whole runs of row-major cells, i.e. a
+    spatial slab) and temperatures are all-gathered in slot order (8 B per
+    particle); normally conduction only involves the few slots the contacts
+    touched, every rank does all of it and nothing is exchanged.
 
 Each element is computed by exactly one rank with the same arithmetic as the
 single-GPU step, so the result is bit-identical for any number of ranks.
@@ -75,9 +77,12 @@ class ShardedParticleSystem(ParticleSystem):
                 torch.cuda.current_stream().synchronize()
             _capi.check(L, L.psim_stage_kick_collide(ctx, ctypes.c_void_p(self._acc.data_ptr())))
             _capi.check(L, L.psim_stage_conduction(ctx, lo, hi, ctypes.c_void_p(self._tmp.data_ptr())))
-            self._gather(self._tmp, per)
-            if self._tdev.type == "cuda":
-                torch.cuda.current_stream().synchronize()
+            exchanges = ctypes.c_int32(0)
+            _capi.check(L, L.psim_stage_conduction_exchanges(ctx, ctypes.byref(exchanges)))
+            if exchanges.value:      # same answer on every rank
+                self._gather(self._tmp, per)
+                if self._tdev.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
             _capi.check(L, L.psim_stage_finish(ctx, ctypes.c_void_p(self._tmp.data_ptr())))
             self._stale = True
             t = (ctypes.c_double * 3)()
