@@ -831,9 +831,12 @@ public:
     // the tree is built, so that it shares the device with the walk (FP64-bound) and not with
     // the tree build (memory-bound like itself).  Joined by join_side_work().
     bool side_running = false;
+    // mark_side_release() is called where the side work may start (tree built), then the walk
+    // is launched, and only then is the side work submitted: its dozen launches would otherwise
+    // sit between the tree build and the walk on the host's submission path.
+    void mark_side_release() { be::event_record(ev_drift, st); }
     void start_side_work()
     {
-        be::event_record(ev_drift, st);
         be::stream_wait(st2, ev_drift);
         build_grid(st2, sort_tmp2);
         if (cfg.stage_mask & kStageCollisions) { detect_count(st2, scan_tmp2, counters2.p); predetected = true; }
@@ -862,9 +865,10 @@ public:
         timer.mark(st, 2);
         build_tree();
         timer.mark(st, 3);
-        if (side) start_side_work();
+        if (side) mark_side_release();
         gravity(acc2.p);
         timer.mark(st, 4);
+        if (side) start_side_work();
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
         join_side_work();
@@ -897,13 +901,15 @@ public:
         timer.mark(st, 2);
         build_tree();
         timer.mark(st, 3);
-        if (side) start_side_work();
     }
     void stage_gravity(int64_t lo, int64_t hi, vec2* acc_sorted)
     {
         if (lo < 0 || hi > n || lo > hi) throw std::invalid_argument("psim: bad sorted range");
+        const bool side = cfg.overlap != 0 && n > 0;
+        if (side) mark_side_release();
         gravity_range(lo, hi, acc_sorted, true);
         timer.mark(st, 4);
+        if (side) start_side_work();
     }
     void stage_kick_collide(const vec2* acc_sorted)
     {
