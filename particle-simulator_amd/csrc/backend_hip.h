@@ -3,6 +3,7 @@
 // sort, exclusive scan, ordered f64 reduction.  64-lane wavefronts throughout.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <math.h>
 #include <stdexcept>
 #include <string>
@@ -72,6 +73,65 @@ inline void* host_alloc_pinned(size_t bytes)
     return p;
 }
 inline void host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
+// ------------------------------------------------------------------ small device-to-host readbacks
+// The step asks the device for a few words many times (counts that size the next
+// launches).  A mailbox is a block of host memory the device can write: one small kernel
+// copies up to two word ranges into it and then raises a sequence number, which the host
+// polls.  That is shorter than a copy engine transfer followed by a stream wait.
+struct Mailbox {
+    static constexpr uint32_t kWords = 1024;     // payload words; the sequence word follows them
+    volatile uint32_t* host = nullptr;
+    uint32_t* dev = nullptr;
+    uint32_t seq = 0;
+};
+inline void mailbox_create(Mailbox& m)
+{
+    void* h = nullptr;
+    PSIM_HIP(hipHostMalloc(&h, (Mailbox::kWords + 16) * sizeof(uint32_t), hipHostMallocMapped));
+    memset(h, 0, (Mailbox::kWords + 16) * sizeof(uint32_t));
+    void* d = nullptr;
+    PSIM_HIP(hipHostGetDevicePointer(&d, h, 0));
+    m.host = (volatile uint32_t*)h;
+    m.dev = (uint32_t*)d;
+    m.seq = 0;
+}
+inline void mailbox_destroy(Mailbox& m)
+{
+    if (m.host) (void)hipHostFree((void*)m.host);
+    m.host = nullptr;
+    m.dev = nullptr;
+}
+__global__ void __launch_bounds__(1024) mailbox_kernel(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb,
+                                                       uint32_t* box, uint32_t seq)
+{
+    uint32_t t = threadIdx.x;
+    if (t < na) box[t] = a[t];
+    else if (t < na + nb) box[t] = b[t - na];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(box + Mailbox::kWords, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// words of a (then of b, may be null / 0) -> dst; returns when they have arrived
+inline void mailbox_fetch(Stream st, Mailbox& m, void* dst, const void* a, uint32_t na, const void* b, uint32_t nb)
+{
+    if (na + nb > Mailbox::kWords) throw std::runtime_error("mailbox_fetch: too many words");
+    uint32_t seq = ++m.seq;
+    if (seq == 0) seq = ++m.seq;
+    hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)a, na, (const uint32_t*)b, nb, m.dev,
+                       seq);
+    PSIM_HIP(hipGetLastError());
+    uint64_t polls = 0;
+    while (m.host[Mailbox::kWords] != seq) {
+        if (++polls == (1ull << 22)) {
+            // long wait: let the runtime report a failed kernel instead of spinning for ever
+            PSIM_HIP(hipStreamSynchronize(st));
+            if (m.host[Mailbox::kWords] != seq) throw std::runtime_error("mailbox_fetch: readback did not arrive");
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    memcpy(dst, (const void*)m.host, (size_t)(na + nb) * 4);
+}
 
 // ------------------------------------------------------------------ launch
 template <class F>

@@ -156,13 +156,12 @@ public:
     int64_t solver_rounds = 0, solver_fixpoint_iters = 0;
     bool count_walk = false;
     be::StageTimer timer;
-    static constexpr size_t kPinnedBytes = 4096;
-    void* pinned = nullptr;
+    be::Mailbox mailbox;
 
     ~Sim()
     {
         timer.destroy();
-        be::host_free_pinned(pinned);
+        be::mailbox_destroy(mailbox);
         be::event_destroy(ev_drift);
         be::event_destroy(ev_side);
         be::stream_destroy(st2);
@@ -170,7 +169,7 @@ public:
 
     explicit Sim(const Config& c) : cfg(c), st(0)
     {
-        pinned = be::host_alloc_pinned(kPinnedBytes);
+        be::mailbox_create(mailbox);
         counters.ensure(16);
         counters2.ensure(16);
         st2 = be::stream_create();
@@ -255,19 +254,29 @@ public:
         be::sync(st);
     }
 
-    // small synchronous readback through the page-locked staging block
+    // small synchronous readback (whole 32-bit words) through the mailbox; with check_fault it
+    // also fetches the word a scan / sort look-back sets if it gave up (asked for where the
+    // values read size the next launches: tree build, step end)
     void readback(void* dst, const void* dev, size_t bytes, bool check_fault = false)
     {
-        if (bytes + 8 > kPinnedBytes) throw std::runtime_error("psim: internal: readback too large");
-        be::copy_d2h(st, pinned, dev, bytes);
-        // with check_fault the readback also fetches the word a scan / sort look-back sets if it
-        // gave up (asked for where the values read size the next launches: tree build, step end)
-        uint32_t* fault = (uint32_t*)((char*)pinned + kPinnedBytes - 8);
-        *fault = 0;
-        if (check_fault) be::copy_d2h(st, fault, be::lookback_fault_word(), 4);
-        be::sync(st);
-        memcpy(dst, pinned, bytes);
-        if (*fault != 0) throw std::runtime_error("psim: internal: scan / sort look-back timed out");
+        readback2(dst, dev, bytes, nullptr, 0, check_fault);
+    }
+    void readback2(void* dst, const void* a, size_t bytes_a, const void* b, size_t bytes_b, bool check_fault = false)
+    {
+        if ((bytes_a | bytes_b) & 3) throw std::runtime_error("psim: internal: readback of partial words");
+        uint32_t na = (uint32_t)(bytes_a / 4), nb = (uint32_t)(bytes_b / 4);
+        if (na + nb + 1 > 256) throw std::runtime_error("psim: internal: readback too large");
+        uint32_t words[256];
+        if (!check_fault) {
+            be::mailbox_fetch(st, mailbox, words, a, na, b, nb);
+        } else if (nb == 0) {
+            be::mailbox_fetch(st, mailbox, words, a, na, be::lookback_fault_word(), 1);
+            if (words[na] != 0) throw std::runtime_error("psim: internal: scan / sort look-back timed out");
+        } else {
+            throw std::runtime_error("psim: internal: readback2 with fault check");
+        }
+        memcpy(dst, words, bytes_a);
+        if (nb) memcpy((char*)dst + bytes_a, words + na, bytes_b);
     }
     uint32_t read_u32(const uint32_t* d)
     {
@@ -640,14 +649,10 @@ public:
         be::exclusive_scan_u32(st, pcount.p, poffs.p, 2ull * nH, scan_tmp.p, counters.p + 5);
         be::launch(st, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
         be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
-        double t[3];
-        be::copy_d2h(st, pinned, red_out.p, 24);
-        be::copy_d2h(st, (char*)pinned + 32, counters.p + 5, 4);
-        be::sync(st);
-        memcpy(t, pinned, 24);
-        uint32_t newly_moved;
-        memcpy(&newly_moved, (char*)pinned + 32, 4);
-        n_moved += newly_moved;
+        struct { double t[3]; uint32_t newly_moved; } back;
+        readback2(&back, red_out.p, 24, counters.p + 5, 4);
+        const double* t = back.t;
+        n_moved += back.newly_moved;
         coll_totals[0] += t[0]; coll_totals[1] += t[1]; coll_totals[2] += t[2];
         n_contacts += nH;
         if (cfg.debug) log_n += nH;
@@ -743,13 +748,9 @@ public:
         be::launch(st, n, k);
         if (!f) return 0;
         // one synchronisation for the explosion count and the sorts' fault word
-        uint32_t two[2];
-        be::copy_d2h(st, pinned, counters.p, 4);
-        be::copy_d2h(st, (char*)pinned + 4, be::lookback_fault_word(), 4);
-        be::sync(st);
-        memcpy(two, pinned, 8);
-        if (two[1] != 0) throw std::runtime_error("psim: internal: radix sort look-back timed out");
-        return two[0];
+        uint32_t count = 0;
+        readback(&count, counters.p, 4, true);
+        return count;
     }
 
     // particle_system.py:651-730

@@ -36,6 +36,15 @@ inline void stream_wait(Stream, Event) {}
 inline void* host_alloc_pinned(size_t bytes) { return calloc(bytes ? bytes : 16, 1); }
 inline void host_free_pinned(void* p) { free(p); }
 
+struct Mailbox { int unused = 0; };
+inline void mailbox_create(Mailbox&) {}
+inline void mailbox_destroy(Mailbox&) {}
+inline void mailbox_fetch(Stream, Mailbox&, void* dst, const void* a, uint32_t na, const void* b, uint32_t nb)
+{
+    if (na) memcpy(dst, a, (size_t)na * 4);
+    if (nb) memcpy((char*)dst + (size_t)na * 4, b, (size_t)nb * 4);
+}
+
 template <class F>
 inline void launch(Stream, int64_t n, const F& f)
 {
