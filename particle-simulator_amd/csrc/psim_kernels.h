@@ -505,6 +505,14 @@ struct TreeCom {
     int depth;
     NodeChildren ch;
     NodeRec* rec;
+    // the same pass for another depth: ids_by_depth holds all node ids sorted by depth,
+    // depth d occupying [lo, lo + cnt)
+    PSIM_HD TreeCom at_level(const uint32_t* ids_by_depth, int d, int64_t lo, int64_t cnt) const
+    {
+        TreeCom t = *this;
+        t.count = cnt; t.ids = ids_by_depth + lo; t.depth = d;
+        return t;
+    }
     PSIM_HD void operator()(int64_t t) const
     {
         uint32_t id = ids[t];
@@ -1006,8 +1014,10 @@ struct SegDisplacement {
     const BodyState* out;
     const CellBody* body;
     double* dseg;
+    uint32_t* zero_word;       // cleared here for the counting pass that follows
     PSIM_HD void operator()(int64_t e) const
     {
+        if (e == 0) *zero_word = 0u;
         uint32_t x = (uint32_t)(adj[e] >> 32);
         if (cseg[x] != (int32_t)e) return;
         double x0 = body[x].x, y0 = body[x].y, m = 0.0;
@@ -1108,6 +1118,22 @@ struct ContactCarryClean {
         uint32_t si, sj;
         decode_pair_key(g, h0keys[h], &si, &sj);
         counts[h] = (cseg[si] < 0 && cseg[sj] < 0) ? 1u : 0u;
+    }
+};
+
+// One launch for the three element ranges of a re-test pass: [0, nt) re-tests, [nt, nt + n0)
+// carried-over clean contacts and, in the count pass, [nt + n0, nt + n0 + nH) the contacts
+// still waiting on a predecessor.
+struct RetestPass {
+    ContactRetest retest;
+    ContactCarryClean carry;
+    CountPending pending;
+    int64_t nt, n0;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        if (i < nt) retest(i);
+        else if (i < nt + n0) carry(i - nt);
+        else pending(i - nt - n0);
     }
 };
 

@@ -432,13 +432,13 @@ public:
             // segments 0..31: depths; segment 32 (kDepthDone): cells finished by TreeEmitNodes
             be::launch(st, (int64_t)m + 1, SegmentOffsets{(int64_t)m, node_depth[sd].p, depth_off.p, (uint32_t)(kKeyLevels + 1)});
             readback(depth_off_host, depth_off.p, sizeof(int32_t) * (kKeyLevels + 2));
+            // one launch per depth, deepest first (folding the small top levels into one
+            // single-workgroup launch was measured and is no faster than their launches)
+            TreeCom t0;
+            t0.count = 0; t0.ids = node_id[sd].p; t0.depth = 0; t0.ch = node_children(); t0.rec = rec.p;
             for (int d = kMaxInternalDepth; d >= 0; --d) {
-                int64_t cnt = depth_off_host[d + 1] - depth_off_host[d];
-                if (cnt <= 0) continue;
-                TreeCom t;
-                t.count = cnt; t.ids = node_id[sd].p + depth_off_host[d]; t.depth = d; t.ch = node_children();
-                t.rec = rec.p;
-                be::launch(st, cnt, t);
+                int64_t cnt = (int64_t)depth_off_host[d + 1] - depth_off_host[d];
+                if (cnt > 0) be::launch(st, cnt, t0.at_level(node_id[sd].p, d, depth_off_host[d], cnt));
             }
         }
         tree_valid = true;
@@ -526,8 +526,7 @@ public:
         uint64_t* k0[2] = {h0[0].p, h0[1].p};
         int s0 = be::radix_sort_pairs<uint64_t>(st, k0, nullptr, n0, 0, key_bits, sort_tmp.p);
         const uint64_t* H0 = h0[s0].p;
-        be::copy_d2d(st, hc[0].p, H0, (size_t)n0 * 8);
-        uint64_t* H = hc[0].p;          // current hypothesis (sorted)
+        const uint64_t* H = H0;         // current hypothesis (sorted); the first one is the initial sweep's list
         int hn_which = 0;
         uint32_t nH = n0;
         uint64_t* adjs = nullptr;
@@ -566,18 +565,19 @@ public:
                 pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)ntot);
                 scan_tmp.ensure_zero(st, be::scan_temp_words((uint64_t)ntot));
                 dseg.ensure(2 * (size_t)nH);
-                be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p});
-                ContactRetest r;
+                be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p,
+                                                         counters.p + 1});
+                RetestPass rp;
+                ContactRetest& r = rp.retest;
                 r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outst.p;
                 r.dseg = dseg.p;
                 r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
-                ContactCarryClean cc{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
+                rp.carry = ContactCarryClean{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
+                rp.pending = CountPending{(int64_t)nH, done.p, counters.p + 1};
+                rp.nt = nt; rp.n0 = n0;
                 for (;;) {
-                    be::dev_memset(st, counters.p + 1, 0, 4);
-                    be::launch(st, nH, CountPending{(int64_t)nH, done.p, counters.p + 1});
-                    be::launch(st, nt, r);
-                    be::launch(st, n0, cc);
+                    be::launch(st, ntot + nH, rp);
                     be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)ntot, scan_tmp.p, counters.p);
                     uint32_t two[2];
                     readback(two, counters.p, 8);
@@ -587,7 +587,8 @@ public:
                     // versions; run further rounds and re-test again
                     if (round > 6 + nH) throw std::runtime_error("psim: internal: contact schedule stalled");
                     run_rounds(6);
-                    be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p});
+                    be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p,
+                                                             counters.p + 1});
                 }
                 if (nNew > ccap) {
                     // growing reallocates every contact buffer: restart the whole sweep
@@ -598,9 +599,8 @@ public:
                 }
                 if (nNew > 0) {
                     r.out_keys = hn[0].p; r.write_pass = 1;
-                    cc.out_keys = hn[0].p; cc.write_pass = 1;
-                    be::launch(st, nt, r);
-                    be::launch(st, n0, cc);
+                    rp.carry.out_keys = hn[0].p; rp.carry.write_pass = 1;
+                    be::launch(st, ntot, rp);
                 }
             }
             // H' == H?  Both are duplicate-free, so equal length + every new key found in the
@@ -615,7 +615,8 @@ public:
             uint64_t* kn[2] = {hn[0].p, hn[1].p};
             hn_which = be::radix_sort_pairs<uint64_t>(st, kn, nullptr, nNew, 0, key_bits, sort_tmp.p);
             be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
-            be::copy_d2d(st, hc[0].p, hn[hn_which].p, (size_t)nNew * 8);
+            hc[0].swap(hn[hn_which]);       // the sorted new list becomes the hypothesis (same capacity)
+            H = hc[0].p;
             nH = nNew;
             if (nH == 0) return;
         }
@@ -648,7 +649,7 @@ public:
         be::launch(st, 2ll * nH, f);
         be::exclusive_scan_u32(st, pcount.p, poffs.p, 2ull * nH, scan_tmp.p, counters.p + 5);
         be::launch(st, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
-        be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+        // (ContactFinalize has already marked every touched slot clean again)
         struct { double t[3]; uint32_t newly_moved; } back;
         readback2(&back, red_out.p, 24, counters.p + 5, 4);
         const double* t = back.t;

@@ -209,3 +209,40 @@ def check_render_feed_and_pair_potential(library):
     pe = -(0.01 * m[iu[0]] * m[iu[1]] / np.sqrt(d2[iu] + 10)).sum()
     np.testing.assert_allclose(s.exact_potential_energy(), pe, rtol=1e-12)
     s.close()
+
+
+def check_exactly_coincident_particles(library):
+    """Two particles at the very same position: the reference subdivides for ever (its node
+    pool overflows, quadtree.py:46-74 -- the oracle reports that); this build keeps them as
+    one bucket below depth 31 and carries on: they exert no force on each other (d^2 = 0,
+    particle_system.py:105), are no contact (:217), exchange heat (:322), and everything
+    stays finite."""
+    import pytest
+    from oracle.oracle import OracleSystem
+    n, bounds = 500, (600, 400)
+    rng = np.random.default_rng(21)
+    pos = rng.random((n, 2)) * np.array(bounds)
+    pos[77] = pos[401]
+    st = dict(positions=pos, masses=rng.uniform(5, 20, (n, 1)), temperatures=rng.uniform(0.05, 0.9, (n, 1)))
+    sim = dict(particle_count=n, min_mass=5.0, max_mass=20.0, gravity_constant=0.01, softening_factor=10,
+               barnes_hut_theta=0.5, min_temp=0.05, max_temp=0.1, heat_transfer_coefficient=0.1,
+               coefficient_of_restitution=0.5, grid_cell_size_multiplier=10.0, position_correction_factor=1.05,
+               collision_solver_iterations=1, explosion_efficiency=0.5, thermal_damping_factor=0.0005)
+    with pytest.raises(RuntimeError):
+        OracleSystem(n, sim, np.random.default_rng(0), bounds, state=st)
+    s = ParticleSystem(n, sim, np.random.default_rng(0), bounds, library=library, state=st, debug=True)
+    s._calculate_gravity()
+    assert np.isfinite(s.accelerations).all()
+    # the pair feels the same field (same position, and no mutual force)
+    np.testing.assert_allclose(s.accelerations[77], s.accelerations[401], rtol=1e-12)
+    t0 = s.temperatures.copy()
+    s.update()
+    assert s.counts()["particles"] == n
+    for name in ("positions", "velocities", "accelerations", "temperatures"):
+        assert np.isfinite(getattr(s, name)).all(), name
+    # the coincident pair conducts heat towards each other (full-sweep conduction path)
+    hot, cold = (77, 401) if t0[77, 0] > t0[401, 0] else (401, 77)
+    d = s.debug_array("delta_temps")
+    assert d[hot] < 0 < d[cold]
+    assert np.isfinite(s.get_energies()).all()
+    s.close()

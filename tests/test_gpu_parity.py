@@ -163,3 +163,7 @@ def test_tree_walk_against_all_pairs():
 
 def test_render_feed_and_pair_potential():
     parity.check_render_feed_and_pair_potential(HIP)
+
+
+def test_exactly_coincident_particles_form_a_bucket():
+    parity.check_exactly_coincident_particles(HIP)

@@ -76,3 +76,7 @@ def test_tree_walk_against_all_pairs():
         brute, _ = s.brute_force_accelerations()
         scale = np.abs(brute).max()
         assert np.abs(s.accelerations - brute).max() <= tol * scale, theta
+
+
+def test_exactly_coincident_particles_form_a_bucket():
+    parity.check_exactly_coincident_particles(HOSTLOOP)
