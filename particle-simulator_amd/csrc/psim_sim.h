@@ -726,8 +726,9 @@ public:
         be::launch(st, nt, k);
         uint64_t* ke[2] = {cond_entries[0].p, cond_entries[1].p};
         int bits = 32 + ceil_log2_u64((uint64_t)n + 1);
-        // targets in ascending slot order; sources of one target in ascending slot order
-        int se = be::radix_sort_pairs<uint64_t>(st, ke, nullptr, ne, 0, bits, sort_tmp.p);
+        // targets in ascending slot order; a stable sort on the target field alone keeps the
+        // sources of one target in the (fixed) order the pairs were written
+        int se = be::radix_sort_pairs<uint64_t>(st, ke, nullptr, ne, 32, bits, sort_tmp.p);
         be::launch(st, ne, ConductionApply{(int64_t)ne, cond_entries[se].p, cbody.p, temp.p, mass.p, cfg.heat_coeff,
                                            cdelta.p});
     }
