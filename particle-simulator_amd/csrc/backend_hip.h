@@ -875,15 +875,17 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 // K fetches and one group's trip hides the others' latency; when the first group
 // finishes, the rest complete one after the other.
 template <int K, bool FOLD, bool WIDE>
-__global__ void __launch_bounds__(256) gravity_walk_multi_kernel(
+__global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
     const double* __restrict__ inv_mass, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,
     double softening)
 {
     static_assert(K >= 2 && K <= 4, "two to four walks per wave");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t s0 = s_begin + ((int64_t)blockIdx.x * 4 + wave) * (64 * K) + lane;
+    // one wave per workgroup: a wave that finishes early frees its slot at once (no LDS is
+    // used, so nothing is gained from larger groups)
+    const int lane = threadIdx.x;
+    const int64_t s0 = s_begin + (int64_t)blockIdx.x * (64 * K) + lane;
     double px[K], py[K], ax[K], ay[K];
     uint32_t until[K], j[K];
 #pragma unroll
@@ -970,11 +972,11 @@ inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out,
                               vec2* out, bool fold, uint32_t w2_lo, double theta2, double g_const, double softening)
 {
     if (hi <= lo) return;
-    int64_t blocks = (hi - lo + 256 * K - 1) / (256 * K);
+    int64_t blocks = (hi - lo + 64 * K - 1) / (64 * K);
     if (blocks > 0x7fffffffLL) throw std::runtime_error("launch_walk_multi: grid too large");
     const bool wide = (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
                            perm, inv_mass, out, w2_lo, theta2, g_const, softening);
     };
     if (fold && !wide) go(gravity_walk_multi_kernel<K, true, false>);
