@@ -368,14 +368,14 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
 // One launch per digit pass ("one sweep"): a first kernel counts, for every pass at
 // once, how many keys carry each digit value (the counts do not depend on the order
 // the earlier passes leave).  A pass kernel's 256-lane workgroup then takes the next
-// 2048-key tile (tile numbers are handed out by an atomic counter, so every tile a
+// 4096-key tile (tile numbers are handed out by an atomic counter, so every tile a
 // workgroup can wait for has already started), ranks it stably (wave-level digit
 // matching by ballot + per-wave LDS counters), publishes its per-digit counts and
 // finds its global offsets by looking back over the tiles before it: a predecessor
 // shows either its own count (keep looking) or the running total up to and including
 // itself (stop).  The tile is reordered in LDS so the stores are contiguous per
 // digit run.  Sorts of at most one tile run every pass inside one workgroup.
-constexpr int kSortItems = 8;
+constexpr int kSortItems = 16;
 constexpr int kSortTile = 256 * kSortItems;
 constexpr int kMaxSortPasses = 8;
 constexpr uint32_t kLookValue = 0x3fffffffu;
