@@ -375,8 +375,10 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
 // shows either its own count (keep looking) or the running total up to and including
 // itself (stop).  The tile is reordered in LDS so the stores are contiguous per
 // digit run.  Sorts of at most one tile run every pass inside one workgroup.
-constexpr int kSortItems = 16;
-constexpr int kSortTile = 256 * kSortItems;
+// keys per lane: 16 (4096-key tiles) for long inputs -- longer digit runs per tile, half as many
+// tiles to look back over; 8 (2048-key tiles) for short ones, which then spread over more CUs
+constexpr int kSortItemsLong = 16, kSortItemsShort = 8;
+constexpr uint64_t kSortLongFrom = 1u << 20;
 constexpr int kMaxSortPasses = 8;
 constexpr uint32_t kLookValue = 0x3fffffffu;
 constexpr uint32_t kLookLocal = 1u << 30;       // this tile's own count
@@ -392,7 +394,7 @@ struct SortShared {
 // among its wave's items of the same digit, s.cnt[w][d] the number of such items in
 // the waves before w, s.dstart[d] where digit d starts in the tile; the return value
 // is the tile's count of digit threadIdx.x.
-template <class KeyT>
+template <class KeyT, int kSortItems>
 __device__ __forceinline__ uint32_t tile_rank(SortShared& s, const KeyT (&key)[kSortItems], uint32_t tile_n, int shift,
                                               uint32_t (&rank)[kSortItems])
 {
@@ -445,9 +447,20 @@ __global__ void __launch_bounds__(256) sort_digit_counts_kernel(const KeyT* keys
     uint64_t lo = (uint64_t)blockIdx.x * items_per_block;
     uint64_t hi = lo + items_per_block;
     if (hi > n) hi = n;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        KeyT k = keys[i];
-        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(uint32_t)(k >> (bit_lo + 8 * p)) & 255u], 1u);
+    // four independent loads in flight per lane before their counts are taken
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        KeyT k[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint64_t idx = i + 256u * u;
+            ok[u] = idx < hi;
+            k[u] = ok[u] ? keys[idx] : (KeyT)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u])
+                for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(uint32_t)(k[u] >> (bit_lo + 8 * p)) & 255u], 1u);
     }
     __syncthreads();
     for (int p = 0; p < passes; ++p) {
@@ -456,11 +469,12 @@ __global__ void __launch_bounds__(256) sort_digit_counts_kernel(const KeyT* keys
     }
 }
 
-template <class KeyT>
+template <class KeyT, int kSortItems>
 __global__ void __launch_bounds__(256) sort_pass_kernel(const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout,
                                                         uint32_t n, int shift, const uint32_t* digit_counts,
                                                         uint32_t* status, uint32_t* next_tile, uint32_t* fault)
 {
+    constexpr int kSortTile = 256 * kSortItems;
     __shared__ SortShared s;
     __shared__ KeyT skey[kSortTile];
     __shared__ uint32_t sval[kSortTile];
@@ -483,7 +497,7 @@ __global__ void __launch_bounds__(256) sort_pass_kernel(const KeyT* kin, const u
         key[k] = valid ? kin[tile_base + off] : (KeyT)0;
         val[k] = (valid && vin) ? vin[tile_base + off] : 0u;
     }
-    const uint32_t mine = tile_rank<KeyT>(s, key, tile_n, shift, rank);
+    const uint32_t mine = tile_rank<KeyT, kSortItems>(s, key, tile_n, shift, rank);
     // publish this tile's count of digit `tid`, then look back
     uint32_t* my_status = status + (size_t)tile * 256 + tid;
     __hip_atomic_store(my_status, (tile == 0 ? kLookInclusive : kLookLocal) | mine, __ATOMIC_RELAXED,
@@ -550,10 +564,11 @@ __global__ void __launch_bounds__(256) sort_pass_kernel(const KeyT* kin, const u
 }
 
 // n <= one tile: every pass in one workgroup, keys staged through LDS between passes
-template <class KeyT>
+template <class KeyT, int kSortItems>
 __global__ void __launch_bounds__(256) sort_one_tile_kernel(const KeyT* kin, const uint32_t* vin, KeyT* kout,
                                                             uint32_t* vout, uint32_t n, int bit_lo, int passes)
 {
+    constexpr int kSortTile = 256 * kSortItems;
     __shared__ SortShared s;
     __shared__ KeyT skey[kSortTile];
     __shared__ uint32_t sval[kSortTile];
@@ -570,7 +585,7 @@ __global__ void __launch_bounds__(256) sort_one_tile_kernel(const KeyT* kin, con
     }
     for (int p = 0; p < passes; ++p) {
         const int shift = bit_lo + 8 * p;
-        (void)tile_rank<KeyT>(s, key, n, shift, rank);
+        (void)tile_rank<KeyT, kSortItems>(s, key, n, shift, rank);
 #pragma unroll
         for (int k = 0; k < kSortItems; ++k) {
             uint32_t off = (uint32_t)(w * (64 * kSortItems) + k * 64 + lane);
@@ -601,24 +616,17 @@ __global__ void __launch_bounds__(256) sort_one_tile_kernel(const KeyT* kin, con
 
 inline size_t sort_temp_words(uint64_t n)
 {
-    uint64_t ntiles = (n + kSortTile - 1) / kSortTile;
+    uint64_t ntiles = (n + 256 * kSortItemsShort - 1) / (256 * kSortItemsShort);      // the finer tiling bounds both
     return (size_t)kMaxSortPasses * (256 + 256 * ntiles) + 64;
 }
 
-// Sorts (keys[, vals]) by key bits [bit_lo, bit_lo + 8 * ceil((bit_hi - bit_lo) / 8)),
-// stable.  k[0]/v[0] hold the input; returns the index (0 or 1) of the buffers holding
-// the result.  temp: sort_temp_words(n) words.
-template <class KeyT>
-inline int radix_sort_pairs(Stream st, KeyT* k[2], uint32_t* v[2], uint64_t n, int bit_lo, int bit_hi,
-                            uint32_t* temp)
+template <class KeyT, int ITEMS>
+inline int radix_sort_pairs_tiled(Stream st, KeyT* k[2], uint32_t* v[2], uint64_t n, int bit_lo, int passes, uint32_t* temp)
 {
-    if (n >= (1ull << 30)) throw std::runtime_error("radix_sort: too many items");
-    if (n <= 1 || bit_hi <= bit_lo) return 0;
-    const int passes = (bit_hi - bit_lo + 7) / 8;
-    if (passes > kMaxSortPasses) throw std::runtime_error("radix_sort: too many digit passes");
+    constexpr int kSortTile = 256 * ITEMS;
     const int result = passes & 1;
     if (n <= (uint64_t)kSortTile) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_one_tile_kernel<KeyT>), dim3(1), dim3(256), 0, st, k[0],
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_one_tile_kernel<KeyT, ITEMS>), dim3(1), dim3(256), 0, st, k[0],
                            v ? v[0] : nullptr, k[result], v ? v[result] : nullptr, (uint32_t)n, bit_lo, passes);
         PSIM_HIP(hipGetLastError());
         return result;
@@ -636,13 +644,29 @@ inline int radix_sort_pairs(Stream st, KeyT* k[2], uint32_t* v[2], uint64_t n, i
     uint32_t* fault = lookback_fault_word();
     int cur = 0;
     for (int p = 0; p < passes; ++p) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_pass_kernel<KeyT>), dim3(ntiles), dim3(256), 0, st, k[cur],
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(sort_pass_kernel<KeyT, ITEMS>), dim3(ntiles), dim3(256), 0, st, k[cur],
                            v ? v[cur] : nullptr, k[cur ^ 1], v ? v[cur ^ 1] : nullptr, (uint32_t)n, bit_lo + 8 * p,
                            digit_counts + p * 256, status + (size_t)p * ntiles * 256, next_tile + p, fault);
         cur ^= 1;
     }
     PSIM_HIP(hipGetLastError());
     return cur;
+}
+
+// Sorts (keys[, vals]) by key bits [bit_lo, bit_lo + 8 * ceil((bit_hi - bit_lo) / 8)),
+// stable.  k[0]/v[0] hold the input; returns the index (0 or 1) of the buffers holding
+// the result.  temp: sort_temp_words(n) words.
+template <class KeyT>
+inline int radix_sort_pairs(Stream st, KeyT* k[2], uint32_t* v[2], uint64_t n, int bit_lo, int bit_hi,
+                            uint32_t* temp)
+{
+    if (n >= (1ull << 30)) throw std::runtime_error("radix_sort: too many items");
+    if (n <= 1 || bit_hi <= bit_lo) return 0;
+    const int passes = (bit_hi - bit_lo + 7) / 8;
+    if (passes > kMaxSortPasses) throw std::runtime_error("radix_sort: too many digit passes");
+    if (n >= kSortLongFrom || n <= 256u * kSortItemsLong)
+        return radix_sort_pairs_tiled<KeyT, kSortItemsLong>(st, k, v, n, bit_lo, passes, temp);
+    return radix_sort_pairs_tiled<KeyT, kSortItemsShort>(st, k, v, n, bit_lo, passes, temp);
 }
 
 // ------------------------------------------------------------------ ordered f64 reduction
