@@ -376,8 +376,8 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
 // itself (stop).  The tile is reordered in LDS so the stores are contiguous per
 // digit run.  Sorts of at most one tile run every pass inside one workgroup.
 // keys per lane: 16 (4096-key tiles) for long inputs -- longer digit runs per tile, half as many
-// tiles to look back over; 8 (2048-key tiles) for short ones, which then spread over more CUs
-constexpr int kSortItemsLong = 16, kSortItemsShort = 8;
+// tiles to look back over; 4 (1024-key tiles) for short ones, which then spread over more CUs
+constexpr int kSortItemsLong = 16, kSortItemsShort = 4;
 constexpr uint64_t kSortLongFrom = 1u << 20;
 constexpr int kMaxSortPasses = 8;
 constexpr uint32_t kLookValue = 0x3fffffffu;
@@ -616,7 +616,11 @@ __global__ void __launch_bounds__(256) sort_one_tile_kernel(const KeyT* kin, con
 
 inline size_t sort_temp_words(uint64_t n)
 {
-    uint64_t ntiles = (n + 256 * kSortItemsShort - 1) / (256 * kSortItemsShort);      // the finer tiling bounds both
+    // enough for any input of at most n keys, whichever tiling it gets
+    const uint64_t ts = 256u * kSortItemsShort, tl = 256u * kSortItemsLong;
+    const uint64_t n_short = n < kSortLongFrom ? n : kSortLongFrom;
+    const uint64_t a = (n_short + ts - 1) / ts, b = (n + tl - 1) / tl;
+    const uint64_t ntiles = a > b ? a : b;
     return (size_t)kMaxSortPasses * (256 + 256 * ntiles) + 64;
 }
 
