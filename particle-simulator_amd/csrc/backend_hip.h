@@ -43,6 +43,13 @@ inline void copy_d2d(Stream st, void* d, const void* s, size_t bytes)
     if (bytes) PSIM_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, st));
 }
 inline void sync(Stream st) { PSIM_HIP(hipStreamSynchronize(st)); }
+inline int compute_units()
+{
+    int dev = 0, cus = 0;
+    PSIM_HIP(hipGetDevice(&dev));
+    PSIM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    return cus > 0 ? cus : 1;
+}
 // a second, non-blocking stream + events: memory-bound stages overlap the FP64-bound walk
 inline Stream stream_create()
 {
@@ -907,13 +914,33 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
     const double* __restrict__ inv_mass, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,
-    double softening)
+    double softening, uint32_t nchunks, uint32_t* __restrict__ chunk_counter)
 {
     static_assert(K >= 2 && K <= 4, "two to four walks per wave");
-    // one wave per workgroup: a wave that finishes early frees its slot at once (no LDS is
-    // used, so nothing is gained from larger groups)
+    // One wave per workgroup (no LDS is used).  With chunk_counter the grid is a fixed number of
+    // waves that take chunks of 64 K targets from a counter until none are left: the walk then
+    // holds a set number of wave slots per SIMD and leaves the rest to the kernels of the other
+    // stream for its whole duration.  The last wave to run dry clears the counters again.
     const int lane = threadIdx.x;
-    const int64_t s0 = s_begin + (int64_t)blockIdx.x * (64 * K) + lane;
+    const uint32_t total_elems_arg = total_elems;
+    uint32_t chunk = blockIdx.x;
+  for (;;) {
+    if (chunk_counter) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&chunk_counter[0], 1u);
+        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        if (chunk >= nchunks) {
+            if (lane == 0 && atomicAdd(&chunk_counter[1], 1u) == gridDim.x - 1) {
+                __hip_atomic_store(&chunk_counter[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&chunk_counter[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    } else if (chunk >= nchunks) {
+        return;
+    }
+    total_elems = total_elems_arg;
+    const int64_t s0 = s_begin + (int64_t)chunk * (64 * K) + lane;
     double px[K], py[K], ax[K], ay[K];
     uint32_t until[K], j[K];
 #pragma unroll
@@ -992,20 +1019,27 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
             acc_out[sorted_out ? (uint32_t)s : p] = a;
         }
     }
+    if (!chunk_counter) return;
+  }
 }
 
 template <int K>
 inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
                               const vec2* spos, const double* smass, const uint32_t* perm, const double* inv_mass,
-                              vec2* out, bool fold, uint32_t w2_lo, double theta2, double g_const, double softening)
+                              vec2* out, bool fold, uint32_t w2_lo, double theta2, double g_const, double softening,
+                              uint32_t* chunk_counter, int64_t resident_waves)
 {
     if (hi <= lo) return;
-    int64_t blocks = (hi - lo + 64 * K - 1) / (64 * K);
-    if (blocks > 0x7fffffffLL) throw std::runtime_error("launch_walk_multi: grid too large");
+    int64_t chunks = (hi - lo + 64 * K - 1) / (64 * K);
+    if (chunks > 0x7fffffffLL) throw std::runtime_error("launch_walk_multi: grid too large");
+    // chunk_counter (two zero words) + resident_waves > 0: a fixed number of waves share the chunks
+    int64_t blocks = chunks;
+    if (chunk_counter && resident_waves > 0 && resident_waves < chunks) blocks = resident_waves;
+    else chunk_counter = nullptr;
     const bool wide = (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
-                           perm, inv_mass, out, w2_lo, theta2, g_const, softening);
+                           perm, inv_mass, out, w2_lo, theta2, g_const, softening, (uint32_t)chunks, chunk_counter);
     };
     if (fold && !wide) go(gravity_walk_multi_kernel<K, true, false>);
     else if (fold) go(gravity_walk_multi_kernel<K, true, true>);

@@ -30,7 +30,7 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
         be::launch_walk_multi<2>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
                                  (const double*)smass.p, (const uint32_t*)perm[sorted_key].p,
                                  (const double*)inv_mass.p, out, walk_fold, (uint32_t)w2_cmp_bits, theta2,
-                                 cfg.gravity_constant, cfg.softening);
+                                 cfg.gravity_constant, cfg.softening, walk_ctr.p, walk_resident_waves());
         return;
     }
     if (cfg.walk_mode == 2) {

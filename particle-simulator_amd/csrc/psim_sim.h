@@ -144,6 +144,19 @@ public:
     // scratch
     DevBuf<uint32_t> sort_tmp, scan_tmp, counters;   // counters: 16 words
     DevBuf<uint32_t> sort_tmp2, scan_tmp2, counters2;   // scratch of the side stream
+    DevBuf<uint32_t> walk_ctr;       // chunk counter of the persistent walk (two words, zero between launches)
+    // Waves the walk keeps resident (0 = one wave per chunk of targets, the whole grid at once).
+    // The other stream's kernels only get wave slots as walk waves retire; up to a few million
+    // particles they fit into the walk's tail, beyond that they would run after it.  From 8 Mi
+    // particles on, the walk therefore holds 7 of the 8 wave slots per SIMD and leaves one to
+    // them throughout (16 Mi: walk 9.8 -> 10.5 ms, wait for the other stream 2.75 -> 0.9 ms).
+    // PSIM_WALK_WAVES=<per SIMD> overrides (kernel experiments).
+    int64_t walk_resident_waves() const
+    {
+        static const char* e = getenv("PSIM_WALK_WAVES");
+        int per_simd = e ? atoi(e) : ((cfg.overlap != 0 && n >= (8ll << 20)) ? 7 : 0);
+        return per_simd > 0 ? (int64_t)be::compute_units() * 4 * per_simd : 0;
+    }
     be::Stream st2;
     be::Event ev_drift, ev_side;
     bool predetected = false;      // sweep 0's count pass already ran on the side stream
@@ -172,6 +185,7 @@ public:
         be::mailbox_create(mailbox);
         counters.ensure(16);
         counters2.ensure(16);
+        walk_ctr.ensure_zero(st, 16);
         st2 = be::stream_create();
         ev_drift = be::event_create();
         ev_side = be::event_create();

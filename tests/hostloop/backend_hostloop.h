@@ -26,6 +26,7 @@ inline void copy_h2d(Stream, void* d, const void* h, size_t bytes) { if (bytes) 
 inline void copy_d2h(Stream, void* h, const void* d, size_t bytes) { if (bytes) memcpy(h, d, bytes); }
 inline void copy_d2d(Stream, void* d, const void* s, size_t bytes) { if (bytes) memmove(d, s, bytes); }
 inline void sync(Stream) {}
+inline int compute_units() { return 1; }
 inline Stream stream_create() { return 1; }
 inline void stream_destroy(Stream) {}
 typedef int Event;
