@@ -17,6 +17,7 @@ s = ParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds)
 s._calculate_gravity()
 ke0, pe0, te0 = s.get_energies()
 p0 = s.get_total_momentum()
+exact0 = s.exact_potential_energy()
 print("default config.json, seed 42, N=2000, bounds 2000x1000, FP64")
 print("step      KE            PE(tree)        TE           total        |  reference total   rel.diff")
 print("%4d %13.6f %15.6f %13.6f %13.6f  |  %15.6f  %.2e" % (0, ke0, pe0, te0, ke0 + pe0 + te0,
@@ -38,3 +39,8 @@ ref_p = (g["s100_velocities"] * g["init_masses"]).sum(axis=0)
 print("reference momentum at step 100: (%+.6e, %+.6e)" % (ref_p[0], ref_p[1]))
 print("max |x - x_ref| after 100 steps: %.3e px; max |T - T_ref|: %.3e" % (
     np.abs(s.positions - g["s100_positions"]).max(), np.abs(s.temperatures - g["s100_temperatures"]).max()))
+exact1 = s.exact_potential_energy()
+print("with the exact softened pairwise potential energy instead of the sibling-cell sum: PE %.6f -> %.6f, "
+      "KE + TE + PE_exact %.6f -> %.6f (%+.3e relative)" % (
+          exact0, exact1, ke0 + te0 + exact0, ke + te + exact1,
+          (ke + te + exact1 - (ke0 + te0 + exact0)) / abs(ke0 + te0 + exact0)))
