@@ -99,9 +99,16 @@ int psim_step(psim_context* ctx, int64_t k_steps);
  * the device buffers (RCCL):
  *   psim_stage_build         drift, grid, tree (identical on every rank)
  *   psim_stage_gravity       walk for the sorted particles [s_lo, s_hi) -> acc_sorted[s]
- *                            (device pointer, (n,2) float64, indexed by sorted position)
- *   -- all-gather acc_sorted --
- *   psim_stage_kick_collide  kick from the gathered accelerations; contact solver
+ *                            (device pointer, (n,2) float64, indexed by sorted position).
+ *                            Returns once the walk is submitted to the context's stream (the
+ *                            device's default stream): an exchange submitted to that stream,
+ *                            or to one that waits for it, is ordered after the walk.
+ *   -- all-gather acc_sorted (may be started asynchronously) --
+ *   psim_stage_settle_positions  optional: the half of the contact solver that needs no
+ *                            velocities (contact list, pushed-apart positions), on the
+ *                            library's second stream while the exchange is in flight;
+ *                            psim_stage_kick_collide does it itself if this was not called
+ *   psim_stage_kick_collide  kick from the gathered accelerations; rest of the contact solver
  *   psim_stage_conduction    conduction + cooling for grid slots [k_lo, k_hi) ->
  *                            temp_slots[k] (device pointer, (n) float64, slot order)
  *   -- all-gather temp_slots --
@@ -109,6 +116,7 @@ int psim_step(psim_context* ctx, int64_t k_steps);
  * Results are bit-identical to psim_step for any split of the ranges. */
 int psim_stage_build(psim_context* ctx);
 int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* acc_sorted);
+int psim_stage_settle_positions(psim_context* ctx);
 int psim_stage_kick_collide(psim_context* ctx, const double* acc_sorted);
 int psim_stage_conduction(psim_context* ctx, int64_t k_lo, int64_t k_hi, double* temp_slots);
 int psim_stage_finish(psim_context* ctx, const double* temp_slots);

@@ -109,15 +109,14 @@ inline void mailbox_destroy(Mailbox& m)
     m.host = nullptr;
     m.dev = nullptr;
 }
-__global__ void __launch_bounds__(1024) mailbox_kernel(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb,
-                                                       uint32_t* box, uint32_t seq)
+// (256 lanes: a workgroup the other stream can place while the walk holds most wave slots)
+__global__ void __launch_bounds__(256) mailbox_kernel(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb,
+                                                      uint32_t* box, uint32_t seq)
 {
-    uint32_t t = threadIdx.x;
-    if (t < na) box[t] = a[t];
-    else if (t < na + nb) box[t] = b[t - na];
+    for (uint32_t t = threadIdx.x; t < na + nb; t += 256) box[t] = t < na ? a[t] : b[t - na];
     __threadfence_system();
     __syncthreads();
-    if (t == 0) __hip_atomic_store(box + Mailbox::kWords, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(box + Mailbox::kWords, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // words of a (then of b, may be null / 0) -> dst; returns when they have arrived
 inline void mailbox_fetch(Stream st, Mailbox& m, void* dst, const void* a, uint32_t na, const void* b, uint32_t nb)
@@ -125,7 +124,7 @@ inline void mailbox_fetch(Stream st, Mailbox& m, void* dst, const void* a, uint3
     if (na + nb > Mailbox::kWords) throw std::runtime_error("mailbox_fetch: too many words");
     uint32_t seq = ++m.seq;
     if (seq == 0) seq = ++m.seq;
-    hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)a, na, (const uint32_t*)b, nb, m.dev,
+    hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(256), 0, st, (const uint32_t*)a, na, (const uint32_t*)b, nb, m.dev,
                        seq);
     PSIM_HIP(hipGetLastError());
     uint64_t polls = 0;
@@ -210,9 +209,10 @@ inline uint32_t* lookback_fault_word()
 
 // ------------------------------------------------------------------ exclusive scan (u32)
 constexpr int kScanItems = 16;
-constexpr int kScanTile = 1024 * kScanItems;
+constexpr int kScanThreads = 256;    // small workgroups: placeable next to a walk that holds most wave slots
+constexpr int kScanTile = kScanThreads * kScanItems;
 
-// One launch for any length: each 1024-lane workgroup takes the next 16384-item tile
+// One launch for any length: each 256-lane workgroup takes the next 4096-item tile
 // (numbered by an atomic counter), scans it, publishes the tile's sum and finds the
 // sum of everything before it by looking back over its predecessors' status words
 // (64 at a time, one per lane of the first wave): a predecessor shows either its own
@@ -221,7 +221,7 @@ constexpr int kScanTile = 1024 * kScanItems;
 // before its first use.
 constexpr uint64_t kScanLocal = 1ull << 62, kScanInclusive = 2ull << 62, kScanValue = (1ull << 62) - 1;
 
-__global__ void __launch_bounds__(1024) scan_lookback_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
+__global__ void __launch_bounds__(kScanThreads) scan_lookback_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
                                                             uint32_t ntiles, uint32_t* temp, uint32_t* total_out,
                                                             uint32_t* fault)
 {
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(1024) scan_lookback_kernel(const uint32_t* in,
     if (tid == 0) s_tile = atomicAdd(&temp[1], 1u);
     __syncthreads();
     if (s_tile == ntiles - 1) {
-        for (uint32_t i = tid; i < ntiles; i += 1024)
+        for (uint32_t i = tid; i < ntiles; i += kScanThreads)
             __hip_atomic_store(status + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {
             __hip_atomic_store(&temp[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -334,21 +334,26 @@ __global__ void __launch_bounds__(1024) scan_lookback_kernel(const uint32_t* in,
     }
 }
 
-// whole scan in one 1024-lane workgroup (n <= 1024 * kScanItems): one launch instead of three
-__global__ void __launch_bounds__(1024) scan_small_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
-                                                          uint32_t* total_out)
+// whole scan in one workgroup (n <= kScanSmall), tile after tile with a running total
+constexpr uint32_t kScanSmall = 4u * kScanTile;
+__global__ void __launch_bounds__(kScanThreads) scan_small_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
+                                                                  uint32_t* total_out)
 {
     __shared__ uint32_t wsum[17];
-    uint32_t base = threadIdx.x * kScanItems;
-    uint32_t v[kScanItems];
-    uint32_t s = 0;
+    uint32_t before = 0;
+    for (uint32_t tile0 = 0; tile0 < n; tile0 += kScanTile) {
+        uint32_t base = tile0 + threadIdx.x * kScanItems;
+        uint32_t v[kScanItems];
+        uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
-    uint32_t total;
-    uint32_t ex = block_exclusive_scan(s, wsum, &total);
+        for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan(s, wsum, &total) + before;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
-    if (threadIdx.x == 0 && total_out) *total_out = total;
+        for (int i = 0; i < kScanItems; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+        before += total;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = before;
 }
 
 inline size_t scan_temp_words(uint64_t n) { return 16 + 2 * (size_t)((n + kScanTile - 1) / kScanTile) + 2; }
@@ -360,13 +365,13 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
 {
     if (n == 0) { if (total_out) dev_memset(st, total_out, 0, 4); return; }
     if (n > 0xfffffff0ull) throw std::runtime_error("exclusive_scan_u32: too many items");
-    if (n <= 1024u * kScanItems) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, out, (uint32_t)n, total_out);
+    if (n <= kScanSmall) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kScanThreads), 0, st, in, out, (uint32_t)n, total_out);
         PSIM_HIP(hipGetLastError());
         return;
     }
     uint32_t nb = (uint32_t)((n + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(scan_lookback_kernel, dim3(nb), dim3(1024), 0, st, in, out, (uint32_t)n, nb, temp, total_out,
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3(nb), dim3(kScanThreads), 0, st, in, out, (uint32_t)n, nb, temp, total_out,
                        lookback_fault_word());
     PSIM_HIP(hipGetLastError());
 }

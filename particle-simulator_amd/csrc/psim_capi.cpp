@@ -185,10 +185,18 @@ int psim_stage_build(psim_context* ctx)
 
 int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* acc_sorted)
 {
+    // not waited for: the caller's exchange is ordered after the walk on the same stream
     PSIM_TRY(ctx && acc_sorted, {
         use_device(ctx->device);
         ctx->sim->stage_gravity(s_lo, s_hi, reinterpret_cast<psim::vec2*>(acc_sorted));
-        psim::be::sync(ctx->sim->st);
+    })
+}
+
+int psim_stage_settle_positions(psim_context* ctx)
+{
+    PSIM_TRY(ctx, {
+        use_device(ctx->device);
+        ctx->sim->stage_settle_positions();
     })
 }
 

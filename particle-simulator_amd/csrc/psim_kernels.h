@@ -880,31 +880,49 @@ struct AdjLinks {
     }
 };
 
-// particle_system.py:200-268 (_resolve_collision_jit), strict FP64, on copies
-// of the two bodies (i = lower particle index).  Returns whether they touched.
-PSIM_HD PSIM_FORCEINLINE bool resolve_pair(BodyState& I, BodyState& J, double mi, double mj, int32_t ri,
-                                           int32_t rj, double G, double soft, double restitution,
-                                           double pos_correct, double* vals)
+// particle_system.py:200-268 (_resolve_collision_jit), strict FP64, in two halves.
+// Whether two particles touch and where the push-apart leaves them depends on
+// positions, masses and radii only (:207-237); the impulse, the energy book-keeping
+// and the heating (:223-225, :239-266) read that half's normal and PE change and the
+// velocities.  The solver therefore settles the contact list and the positions first
+// (while the tree walk is still running, since none of it needs the new accelerations)
+// and runs the velocity half once over the final list.
+//
+// Position half on copies of the two positions (i = lower particle index).  geo =
+// {nx, ny, pe_change}; a pair that does not touch leaves geo = 0 (a unit normal never is).
+PSIM_HD PSIM_FORCEINLINE bool resolve_pair_positions(vec2& Pi, vec2& Pj, double mi, double mj, int32_t ri, int32_t rj,
+                                                     double G, double soft, double pos_correct, double* geo)
 {
     int64_t min_dist = (int64_t)ri + (int64_t)rj;
-    double dvx = J.pos.x - I.pos.x, dvy = J.pos.y - I.pos.y;
+    double dvx = Pj.x - Pi.x, dvy = Pj.y - Pi.y;
     double d2 = dvx * dvx + dvy * dvy;
-    vals[0] = 0.0; vals[1] = 0.0; vals[2] = 0.0;
+    geo[0] = 0.0; geo[1] = 0.0; geo[2] = 0.0;
     if (!(d2 < (double)(min_dist * min_dist) && d2 > 0)) return false;
     double dist = sqrt(d2);
     double M = mi + mj;
-    double vib0 = I.vel.x, vib1 = I.vel.y, vjb0 = J.vel.x, vjb1 = J.vel.y;
-    double ke_before = 0.5 * mi * (vib0 * vib0 + vib1 * vib1) + 0.5 * mj * (vjb0 * vjb0 + vjb1 * vjb1);
     double pe_before = (-G * mi * mj) / sqrt(d2 + soft);
     double overlap = ((double)min_dist - dist) * pos_correct;
     double nx = dvx / dist, ny = dvy / dist;
     double ci = (mj / M) * overlap, cj = (mi / M) * overlap;
-    I.pos.x -= ci * nx; I.pos.y -= ci * ny;
-    J.pos.x += cj * nx; J.pos.y += cj * ny;
-    double fx = J.pos.x - I.pos.x, fy = J.pos.y - I.pos.y;
+    Pi.x -= ci * nx; Pi.y -= ci * ny;
+    Pj.x += cj * nx; Pj.y += cj * ny;
+    double fx = Pj.x - Pi.x, fy = Pj.y - Pi.y;
     double fd2 = fx * fx + fy * fy;
     double pe_after = (-G * mi * mj) / sqrt(fd2 + soft);
-    double pe_change = pe_after - pe_before;
+    geo[0] = nx; geo[1] = ny; geo[2] = pe_after - pe_before;
+    return true;
+}
+
+// Velocity half.  vals = {pe_change, ke_lost, heat}.
+PSIM_HD PSIM_FORCEINLINE void resolve_pair_velocities(VelState& I, VelState& J, double mi, double mj, const double* geo,
+                                                      double restitution, double* vals)
+{
+    double nx = geo[0], ny = geo[1], pe_change = geo[2];
+    vals[0] = 0.0; vals[1] = 0.0; vals[2] = 0.0;
+    if (nx == 0.0 && ny == 0.0) return;
+    double M = mi + mj;
+    double vib0 = I.vel.x, vib1 = I.vel.y, vjb0 = J.vel.x, vjb1 = J.vel.y;
+    double ke_before = 0.5 * mi * (vib0 * vib0 + vib1 * vib1) + 0.5 * mj * (vjb0 * vjb0 + vjb1 * vjb1);
     double vrx = vjb0 - vib0, vry = vjb1 - vib1;
     double vrn = vrx * nx + vry * ny;
     if (vrn < 0) {
@@ -922,12 +940,11 @@ PSIM_HD PSIM_FORCEINLINE bool resolve_pair(BodyState& I, BodyState& J, double mi
         J.temp += (heat * 0.5) / mj;
     }
     vals[0] = pe_change; vals[1] = ke_lost; vals[2] = heat;
-    return true;
 }
 
-// One round of executing the hypothesised contacts in dependency order: contact
-// h runs once the previous contact of each of its two slots ran in an EARLIER
-// round (done[] holds the round number, 0 = not yet).
+// One round of executing the hypothesised contacts' position halves in dependency
+// order: contact h runs once the previous contact of each of its two slots ran in an
+// EARLIER round (done[] holds the round number, 0 = not yet).
 struct ContactSimulate {
     int64_t n;
     const uint32_t* hsi;
@@ -935,25 +952,15 @@ struct ContactSimulate {
     const int32_t* prev;
     uint32_t* done;
     uint32_t round;
-    BodyState* out;           // [2h + side]
-    double* vals;             // [3h]
+    vec2* out;                // [2h + side] position after contact h
+    double* geo;              // [3h] normal and PE change
     uint32_t* executed;
-    // initial state
-    const CellBody* body;
-    const vec2* vel;
-    const double* temp;
+    const CellBody* body;     // initial positions
     const double* mass;
-    double G, soft, restitution, pos_correct;
-    PSIM_HD BodyState fetch(uint32_t slot, int32_t pr) const
+    double G, soft, pos_correct;
+    PSIM_HD vec2 fetch(uint32_t slot, int32_t pr) const
     {
-        if (pr < 0) {
-            BodyState s;
-            uint32_t p = body[slot].idx;
-            s.pos = body_pos(body[slot]);
-            s.vel = vel[p];
-            s.temp = temp[p];
-            return s;
-        }
+        if (pr < 0) return body_pos(body[slot]);
         int side = (hsi[pr] == slot) ? 0 : 1;
         return out[2 * (uint32_t)pr + side];
     }
@@ -964,15 +971,59 @@ struct ContactSimulate {
         if (pi >= 0) { uint32_t d = done[pi]; if (d == 0 || d == round) return; }
         if (pj >= 0) { uint32_t d = done[pj]; if (d == 0 || d == round) return; }
         uint32_t si = hsi[h], sj = hsj[h];
-        BodyState I = fetch(si, pi), J = fetch(sj, pj);
+        vec2 I = fetch(si, pi), J = fetch(sj, pj);
         double v[3];
-        resolve_pair(I, J, mass[body[si].idx], mass[body[sj].idx], body[si].r, body[sj].r, G, soft, restitution,
-                     pos_correct, v);
+        resolve_pair_positions(I, J, mass[body[si].idx], mass[body[sj].idx], body[si].r, body[sj].r, G, soft,
+                               pos_correct, v);
+        out[2 * h] = I;
+        out[2 * h + 1] = J;
+        geo[3 * h] = v[0]; geo[3 * h + 1] = v[1]; geo[3 * h + 2] = v[2];
+        done[h] = round;
+        aggregated_inc(executed);
+    }
+};
+
+// Velocity halves of the settled contact list, in the same dependency rounds: contact
+// h runs in the round its position half ran in (done[h]), so the previous contact of
+// each of its slots has run before it.
+struct ContactVelocity {
+    int64_t n;
+    const uint32_t* hsi;
+    const uint32_t* hsj;
+    const int32_t* prev;
+    const uint32_t* done;
+    uint32_t round;
+    VelState* out;            // [2h + side]
+    const double* geo;        // [3h]
+    double* vals;             // [3h] pe_change, ke_lost, heat
+    const CellBody* body;
+    const vec2* vel;          // initial state
+    const double* temp;
+    const double* mass;
+    double restitution;
+    PSIM_HD VelState fetch(uint32_t slot, int32_t pr) const
+    {
+        if (pr < 0) {
+            VelState s;
+            uint32_t p = body[slot].idx;
+            s.vel = vel[p];
+            s.temp = temp[p];
+            s.unused = 0.0;
+            return s;
+        }
+        int side = (hsi[pr] == slot) ? 0 : 1;
+        return out[2 * (uint32_t)pr + side];
+    }
+    PSIM_HD void operator()(int64_t h) const
+    {
+        if (done[h] != round) return;
+        uint32_t si = hsi[h], sj = hsj[h];
+        VelState I = fetch(si, prev[2 * h]), J = fetch(sj, prev[2 * h + 1]);
+        double v[3];
+        resolve_pair_velocities(I, J, mass[body[si].idx], mass[body[sj].idx], geo + 3 * h, restitution, v);
         out[2 * h] = I;
         out[2 * h + 1] = J;
         vals[3 * h] = v[0]; vals[3 * h + 1] = v[1]; vals[3 * h + 2] = v[2];
-        done[h] = round;
-        aggregated_inc(executed);
     }
 };
 
@@ -987,7 +1038,7 @@ struct CountPending {
 // output of its last hypothesised contact ordered before t, else the initial one
 PSIM_HD PSIM_FORCEINLINE vec2 versioned_pos(uint32_t slot, uint64_t t, const int32_t* cseg, const uint64_t* adj,
                                             int64_t n_adj, const uint64_t* hkeys, const uint32_t* hsi,
-                                            const BodyState* out, const CellBody* body)
+                                            const vec2* out, const CellBody* body)
 {
     int32_t e0 = cseg[slot];
     int64_t last = -1;
@@ -999,7 +1050,7 @@ PSIM_HD PSIM_FORCEINLINE vec2 versioned_pos(uint32_t slot, uint64_t t, const int
     }
     if (last < 0) return body_pos(body[slot]);
     int side = (hsi[last] == slot) ? 0 : 1;
-    return out[2 * last + side].pos;
+    return out[2 * last + side];
 }
 
 // For each touched slot: how far any of its versioned positions lies from its
@@ -1011,7 +1062,7 @@ struct SegDisplacement {
     const uint64_t* adj;
     const int32_t* cseg;
     const uint32_t* hsi;
-    const BodyState* out;
+    const vec2* out;
     const CellBody* body;
     double* dseg;
     uint32_t* zero_word;       // cleared here for the counting pass that follows
@@ -1024,7 +1075,7 @@ struct SegDisplacement {
         for (int64_t k = e; k < n_adj && (uint32_t)(adj[k] >> 32) == x; ++k) {
             uint32_t h = (uint32_t)adj[k];
             int side = (hsi[h] == x) ? 0 : 1;
-            vec2 p = out[2 * h + side].pos;
+            vec2 p = out[2 * h + side];
             double dx = p.x - x0, dy = p.y - y0;
             double d2 = dx * dx + dy * dy;
             m = d2 > m ? d2 : m;
@@ -1047,7 +1098,7 @@ struct ContactRetest {
     const int32_t* cseg;
     const uint64_t* hkeys;
     const uint32_t* hsi;
-    const BodyState* out;
+    const vec2* out;
     const double* dseg;
     uint32_t* counts;
     const uint32_t* offsets;
@@ -1175,17 +1226,15 @@ struct ResetSeg {
     PSIM_HD void operator()(int64_t e) const { cseg[(uint32_t)(adj[e] >> 32)] = -1; }
 };
 
-// converged: write each touched slot's final state back (index space + slot copy)
-struct ContactFinalize {
+// converged: write each touched slot's final position back (index space + slot copy)
+struct ContactFinalizePositions {
     int64_t n_adj;
     const uint64_t* adj;
     int32_t* cseg;
     const uint32_t* hsi;
-    const BodyState* out;
+    const vec2* out;
     CellBody* body;
     vec2* pos;
-    vec2* vel;
-    double* temp;
     uint8_t* moved;           // slot -> touched by a contact this step
     uint32_t* newly;          // [entry] 1 where a slot is touched for the first time this step
     PSIM_HD void operator()(int64_t e) const
@@ -1197,12 +1246,32 @@ struct ContactFinalize {
         moved[x] = 1;
         uint32_t h = (uint32_t)adj[e];
         int side = (hsi[h] == x) ? 0 : 1;
-        BodyState s = out[2 * h + side];
-        uint32_t p = body[x].idx;
+        vec2 s = out[2 * h + side];
         cseg[x] = -1;
-        body[x].x = s.pos.x;
-        body[x].y = s.pos.y;
-        pos[p] = s.pos;
+        body[x].x = s.x;
+        body[x].y = s.y;
+        pos[body[x].idx] = s;
+    }
+};
+
+// ... and, after the velocity pass, its final velocity and temperature
+struct ContactFinalizeVelocities {
+    int64_t n_adj;
+    const uint64_t* adj;
+    const uint32_t* hsi;
+    const VelState* out;
+    const CellBody* body;
+    vec2* vel;
+    double* temp;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t x = (uint32_t)(adj[e] >> 32);
+        bool last = (e + 1 == n_adj) || ((uint32_t)(adj[e + 1] >> 32) != x);
+        if (!last) return;
+        uint32_t h = (uint32_t)adj[e];
+        int side = (hsi[h] == x) ? 0 : 1;
+        VelState s = out[2 * h + side];
+        uint32_t p = body[x].idx;
         vel[p] = s.vel;
         temp[p] = s.temp;
     }

@@ -126,7 +126,9 @@ public:
     uint32_t n_moved = 0, n_coincident = 0;
     bool moved_valid = false;      // moved / moved_list describe this step's collision stage
     DevBuf<int32_t> prevl;
-    DevBuf<BodyState> outst;
+    DevBuf<vec2> outp;             // [2h + side] position after hypothesised contact h
+    DevBuf<VelState> outv;         // [2h + side] velocity and temperature after settled contact h
+    DevBuf<double> cgeo;           // [3h] contact normal and PE change
     DevBuf<double> cvals, sum_pe, sum_ke, sum_heat, dseg;
     DevBuf<int32_t> log_ij;
     DevBuf<double> log_vals, delta_dbg;
@@ -146,19 +148,57 @@ public:
     DevBuf<uint32_t> sort_tmp2, scan_tmp2, counters2;   // scratch of the side stream
     DevBuf<uint32_t> walk_ctr;       // chunk counter of the persistent walk (two words, zero between launches)
     // Waves the walk keeps resident (0 = one wave per chunk of targets, the whole grid at once).
-    // The other stream's kernels only get wave slots as walk waves retire; up to a few million
-    // particles they fit into the walk's tail, beyond that they would run after it.  From 8 Mi
-    // particles on, the walk therefore holds 7 of the 8 wave slots per SIMD and leaves one to
-    // them throughout (16 Mi: walk 9.8 -> 10.5 ms, wait for the other stream 2.75 -> 0.9 ms).
-    // PSIM_WALK_WAVES=<per SIMD> overrides (kernel experiments).
+    // A whole-grid walk is dispatched ahead of anything the other stream submits: that stream's
+    // kernels only get wave slots once the walk's last workgroup has been placed.  With the side
+    // stream in use the walk therefore runs as a fixed set of waves that take chunks of targets
+    // from a counter and leave the remaining slots of every SIMD to the other stream for the
+    // whole walk.  What runs there is latency-bound and slows down by about the share of slots
+    // it is denied, while the walk slows down less than its share (4 Mi: 4.15 / 4.32 / 4.71 /
+    // 5.15 ms at 8 / 7 / 6 / 5 slots), so:
+    //   below 8 Mi particles the grid build and the whole position half of the collision stage
+    //   run underneath 6 of 8 slots (4 Mi: step 6.5 -> 6.2 ms);
+    //   from 8 Mi on only the grid build and the first count pass do, underneath 7 of 8 -- the
+    //   position half would not finish under the walk at any setting that pays (16 Mi: 7 slots
+    //   18.7 ms, 6 slots 18.9 ms, against 17.6 ms with the position half after the walk).
+    // PSIM_WALK_WAVES=<per SIMD> and PSIM_POSITIONS_UNDER_WALK=<0|1> override (kernel experiments).
+    bool sharded_step = false;     // the step in progress is driven through the stage_* calls
+    bool positions_under_walk() const
+    {
+        static const char* e = getenv("PSIM_POSITIONS_UNDER_WALK");
+        if (e) return atoi(e) != 0;
+        return cfg.overlap != 0 && (n < (8ll << 20) || sharded_step);
+    }
     int64_t walk_resident_waves() const
     {
         static const char* e = getenv("PSIM_WALK_WAVES");
-        int per_simd = e ? atoi(e) : ((cfg.overlap != 0 && n >= (8ll << 20)) ? 7 : 0);
+        int per_simd = 0;
+        if (e) per_simd = atoi(e);
+        else if (cfg.overlap != 0 && n > 0) {
+            if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
+            else per_simd = (n < (8ll << 20)) ? 6 : 7;
+        }
         return per_simd > 0 ? (int64_t)be::compute_units() * 4 * per_simd : 0;
     }
     be::Stream st2;
     be::Event ev_drift, ev_side;
+    // A lane = a stream with the scratch its sorts, scans and small readbacks use.  The
+    // position half of the collision stage runs on the side lane underneath the walk.
+    struct Lane {
+        be::Stream s;
+        DevBuf<uint32_t>* sort_tmp;
+        DevBuf<uint32_t>* scan_tmp;
+        uint32_t* ctr;             // 16 words
+        be::Mailbox* box;
+    };
+    Lane main_lane() { return Lane{st, &sort_tmp, &scan_tmp, counters.p, &mailbox}; }
+    Lane side_lane() { return Lane{st2, &sort_tmp2, &scan_tmp2, counters2.p, &mailbox2}; }
+    // what the position half leaves for the velocity half of the same sweep
+    uint32_t settled_contacts = 0, settled_rounds = 0;
+    uint64_t* settled_adj = nullptr;
+    bool positions_settled = false;    // sweep 0's position half has run for this step
+    uint32_t cond_ne = 0;              // conduction entries (sorted) waiting for ConductionApply
+    int cond_sorted = 0;
+    bool cond_pairs_ready = false;
     bool predetected = false;      // sweep 0's count pass already ran on the side stream
     DevBuf<double> red_tmp, red_out, terms[4];
 
@@ -169,12 +209,13 @@ public:
     int64_t solver_rounds = 0, solver_fixpoint_iters = 0;
     bool count_walk = false;
     be::StageTimer timer;
-    be::Mailbox mailbox;
+    be::Mailbox mailbox, mailbox2;
 
     ~Sim()
     {
         timer.destroy();
         be::mailbox_destroy(mailbox);
+        be::mailbox_destroy(mailbox2);
         be::event_destroy(ev_drift);
         be::event_destroy(ev_side);
         be::stream_destroy(st2);
@@ -183,6 +224,7 @@ public:
     explicit Sim(const Config& c) : cfg(c), st(0)
     {
         be::mailbox_create(mailbox);
+        be::mailbox_create(mailbox2);
         counters.ensure(16);
         counters2.ensure(16);
         walk_ctr.ensure_zero(st, 16);
@@ -277,14 +319,19 @@ public:
     }
     void readback2(void* dst, const void* a, size_t bytes_a, const void* b, size_t bytes_b, bool check_fault = false)
     {
+        readback_on(main_lane(), dst, a, bytes_a, b, bytes_b, check_fault);
+    }
+    void readback_on(const Lane& ln, void* dst, const void* a, size_t bytes_a, const void* b = nullptr, size_t bytes_b = 0,
+                     bool check_fault = false)
+    {
         if ((bytes_a | bytes_b) & 3) throw std::runtime_error("psim: internal: readback of partial words");
         uint32_t na = (uint32_t)(bytes_a / 4), nb = (uint32_t)(bytes_b / 4);
         if (na + nb + 1 > 256) throw std::runtime_error("psim: internal: readback too large");
         uint32_t words[256];
         if (!check_fault) {
-            be::mailbox_fetch(st, mailbox, words, a, na, b, nb);
+            be::mailbox_fetch(ln.s, *ln.box, words, a, na, b, nb);
         } else if (nb == 0) {
-            be::mailbox_fetch(st, mailbox, words, a, na, be::lookback_fault_word(), 1);
+            be::mailbox_fetch(ln.s, *ln.box, words, a, na, be::lookback_fault_word(), 1);
             if (words[na] != 0) throw std::runtime_error("psim: internal: scan / sort look-back timed out");
         } else {
             throw std::runtime_error("psim: internal: readback2 with fault check");
@@ -292,10 +339,11 @@ public:
         memcpy(dst, words, bytes_a);
         if (nb) memcpy((char*)dst + bytes_a, words + na, bytes_b);
     }
-    uint32_t read_u32(const uint32_t* d)
+    uint32_t read_u32(const uint32_t* d) { return read_u32(main_lane(), d); }
+    uint32_t read_u32(const Lane& ln, const uint32_t* d)
     {
         uint32_t v = 0;
-        readback(&v, d, 4);
+        readback_on(ln, &v, d, 4);
         return v;
     }
 
@@ -470,57 +518,92 @@ public:
     void gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out);
 
     // particle_system.py:439-474
-    void ensure_contact_capacity(size_t want)
+    void ensure_contact_capacity(const Lane& ln, size_t want)
     {
         if (want <= ccap) return;
         size_t c = want + want / 4 + 1024;
         for (int i = 0; i < 2; ++i) { h0[i].ensure(c); hc[i].ensure(c); hn[i].ensure(c); adj[i].ensure(2 * c); }
-        hsi.ensure(c); hsj.ensure(c); done.ensure(c); prevl.ensure(2 * c); outst.ensure(2 * c); cvals.ensure(3 * c);
+        hsi.ensure(c); hsj.ensure(c); done.ensure(c); prevl.ensure(2 * c); outp.ensure(2 * c); outv.ensure(2 * c);
+        cgeo.ensure(3 * c); cvals.ensure(3 * c);
         sum_pe.ensure(c); sum_ke.ensure(c); sum_heat.ensure(c);
-        sort_tmp.ensure(be::sort_temp_words(2 * c));
+        ln.sort_tmp->ensure(be::sort_temp_words(2 * c));
         ccap = c;
+    }
+
+    // The collision stage in two halves (see resolve_pair_positions): collisions_positions()
+    // settles sweep 0's contact list and the pushed-apart positions on the given lane -- none
+    // of it reads velocities, so it may run while the walk does; collisions_velocities() then
+    // runs, on the main stream and after the kick, the velocity half of that sweep and both
+    // halves of any further sweep (particle_system.py:453-470).
+    void collisions_positions(const Lane& ln)
+    {
+        coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0;
+        n_candidates = 0; n_contacts = 0; log_n = 0; solver_rounds = 0; solver_fixpoint_iters = 0;
+        n_moved = 0; n_coincident = 0;
+        settled_contacts = 0; settled_rounds = 0; settled_adj = nullptr;
+        cond_pairs_ready = false;
+        positions_settled = true;
+        if (n == 0 || cfg.solver_iterations <= 0) return;
+        if (!cseg_ready || cseg.cap < (size_t)n) {
+            cseg.ensure((size_t)n);
+            be::launch(ln.s, (int64_t)cseg.cap, FillI32{(int64_t)cseg.cap, cseg.p, -1});
+            cseg_ready = true;
+        }
+        if (ccap == 0) ensure_contact_capacity(ln, (size_t)n / 16 + 1024);
+        ln.sort_tmp->ensure(be::sort_temp_words(2 * ccap));
+        moved.ensure((size_t)n);
+        moved_list.ensure((size_t)n);
+        be::dev_memset(ln.s, moved.p, 0, (size_t)n);
+        sweep_positions(ln, 0);
+        if (cfg.solver_iterations == 1) {
+            moved_valid = true;
+            if (sparse_conduction_possible()) conduction_sparse_pairs(ln);
+        }
+    }
+
+    void collisions_velocities()
+    {
+        if (n == 0 || cfg.solver_iterations <= 0) { moved_valid = cfg.solver_iterations > 0; return; }
+        Lane ln = main_lane();
+        sweep_velocities(0);
+        for (int it = 1; it < cfg.solver_iterations; ++it) {
+            sweep_positions(ln, it);
+            sweep_velocities(it);
+        }
+        moved_valid = true;
+        if (sparse_conduction_possible() && !cond_pairs_ready) conduction_sparse_pairs(ln);
     }
 
     void collisions()
     {
-        coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0;
-        n_candidates = 0; n_contacts = 0; log_n = 0; solver_rounds = 0; solver_fixpoint_iters = 0;
-        if (n == 0) return;
-        if (!cseg_ready || cseg.cap < (size_t)n) {
-            cseg.ensure((size_t)n);
-            be::launch(st, (int64_t)cseg.cap, FillI32{(int64_t)cseg.cap, cseg.p, -1});
-            cseg_ready = true;
-        }
-        if (ccap == 0) ensure_contact_capacity((size_t)n / 16 + 1024);
-        moved.ensure((size_t)n);
-        moved_list.ensure((size_t)n);
-        be::dev_memset(st, moved.p, 0, (size_t)n);
-        n_moved = 0; n_coincident = 0;
-        for (int it = 0; it < cfg.solver_iterations; ++it) collision_sweep(it);
-        moved_valid = cfg.solver_iterations > 0;
+        collisions_positions(main_lane());
+        collisions_velocities();
     }
 
-    void collision_sweep(int sweep)
+    void sweep_positions(const Lane& ln, int sweep)
     {
         GridView g = grid_view();
         const int slot_field_bits = ceil_log2_u64((uint64_t)n + 1);
+        uint32_t* const ctr = ln.ctr;
+        DevBuf<uint32_t>& scan_scratch = *ln.scan_tmp;
+        settled_contacts = 0; settled_rounds = 0; settled_adj = nullptr;
         // ---- sweep against the initial positions (count, scan, write)
         uint32_t n0 = 0, cand = 0;
         int key_bits = 64;
         const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
         {
-            const uint32_t* ctr = counters.p;
+            const uint32_t* dctr = ctr;
             if (sweep == 0 && predetected) {
-                ctr = counters2.p;          // already computed on the side stream (joined by the caller)
+                dctr = counters2.p;         // already computed on the side stream (this lane, or joined by the caller)
                 predetected = false;
             } else {
-                detect_count(st, scan_tmp, counters.p);
+                detect_count(ln.s, scan_scratch, ctr);
             }
             ContactDetect d;
             d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
             d.coincident_counter = nullptr;
             uint32_t three[4];
-            readback(three, ctr, 16);
+            readback_on(ln, three, dctr, 16);
             n0 = three[0]; cand = three[1];
             if (sweep == 0) n_coincident = three[3];
             slot_bits = ceil_log2_u64((uint64_t)three[2] + 1);
@@ -529,45 +612,45 @@ public:
             key_bits = ceil_log2_u64((uint64_t)cells) + 4 + 2 * slot_bits;
             if (key_bits > 64) throw std::runtime_error("psim: grid cell population too large for the pair-key layout");
             if (n0 > 0) {
-                ensure_contact_capacity(n0);
+                ensure_contact_capacity(ln, n0);
                 d.g = g;
                 d.out_keys = h0[0].p; d.write_pass = 1; d.cand_counter = nullptr;
-                be::launch(st, n, d);
+                be::launch(ln.s, n, d);
             }
         }
         n_candidates += cand;
         if (n0 == 0) return;
         uint64_t* k0[2] = {h0[0].p, h0[1].p};
-        int s0 = be::radix_sort_pairs<uint64_t>(st, k0, nullptr, n0, 0, key_bits, sort_tmp.p);
+        int s0 = be::radix_sort_pairs<uint64_t>(ln.s, k0, nullptr, n0, 0, key_bits, ln.sort_tmp->p);
         const uint64_t* H0 = h0[s0].p;
         const uint64_t* H = H0;         // current hypothesis (sorted); the first one is the initial sweep's list
         int hn_which = 0;
         uint32_t nH = n0;
         uint64_t* adjs = nullptr;
+        uint32_t round = 0;
         for (int iter = 0;; ++iter) {
             ++solver_fixpoint_iters;
             if (iter > 100000) throw std::runtime_error("psim: collision solver did not converge");
             // ---- execute the hypothesis in order
-            be::launch(st, nH, ContactDecode{(int64_t)nH, g, H, hsi.p, hsj.p, adj[0].p, done.p});
+            be::launch(ln.s, nH, ContactDecode{(int64_t)nH, g, H, hsi.p, hsj.p, adj[0].p, done.p});
             uint64_t* ka[2] = {adj[0].p, adj[1].p};
             // entries are generated in ascending contact order, so a stable sort on the slot
             // field alone leaves each slot's contacts in order
-            int sa = be::radix_sort_pairs<uint64_t>(st, ka, nullptr, 2ull * nH, 32, 32 + slot_field_bits, sort_tmp.p);
+            int sa = be::radix_sort_pairs<uint64_t>(ln.s, ka, nullptr, 2ull * nH, 32, 32 + slot_field_bits, ln.sort_tmp->p);
             adjs = adj[sa].p;
-            be::launch(st, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p});
+            be::launch(ln.s, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p});
             // Dependency rounds.  A first batch is launched without asking how far it got (a
             // round with nothing ready is a no-op); whether contacts are still pending is read
             // back together with the re-test count below, and only then are more rounds run.
-            uint32_t round = 0;
+            round = 0;
             auto run_rounds = [&](int count) {
                 for (int b = 0; b < count; ++b) {
                     ++round;
-                    ContactSimulate s;
-                    s.n = nH; s.hsi = hsi.p; s.hsj = hsj.p; s.prev = prevl.p; s.done = done.p; s.round = round;
-                    s.out = outst.p; s.vals = cvals.p; s.executed = counters.p + 3; s.body = cbody.p;
-                    s.vel = vel.p; s.temp = temp.p; s.mass = mass.p; s.G = cfg.gravity_constant;
-                    s.soft = cfg.softening; s.restitution = cfg.restitution; s.pos_correct = cfg.pos_correct;
-                    be::launch(st, nH, s);
+                    ContactSimulate sm;
+                    sm.n = nH; sm.hsi = hsi.p; sm.hsj = hsj.p; sm.prev = prevl.p; sm.done = done.p; sm.round = round;
+                    sm.out = outp.p; sm.geo = cgeo.p; sm.executed = ctr + 3; sm.body = cbody.p;
+                    sm.mass = mass.p; sm.G = cfg.gravity_constant; sm.soft = cfg.softening; sm.pos_correct = cfg.pos_correct;
+                    be::launch(ln.s, nH, sm);
                 }
                 solver_rounds += count;
             };
@@ -577,64 +660,90 @@ public:
             {
                 int64_t nt = 20ll * nH, ntot = nt + n0;
                 pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)ntot);
-                scan_tmp.ensure_zero(st, be::scan_temp_words((uint64_t)ntot));
+                scan_scratch.ensure_zero(ln.s, be::scan_temp_words((uint64_t)ntot));
                 dseg.ensure(2 * (size_t)nH);
-                be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p,
-                                                         counters.p + 1});
+                be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 1});
                 RetestPass rp;
                 ContactRetest& r = rp.retest;
-                r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outst.p;
+                r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outp.p;
                 r.dseg = dseg.p;
                 r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
                 rp.carry = ContactCarryClean{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
-                rp.pending = CountPending{(int64_t)nH, done.p, counters.p + 1};
+                rp.pending = CountPending{(int64_t)nH, done.p, ctr + 1};
                 rp.nt = nt; rp.n0 = n0;
                 for (;;) {
-                    be::launch(st, ntot + nH, rp);
-                    be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)ntot, scan_tmp.p, counters.p);
+                    be::launch(ln.s, ntot + nH, rp);
+                    be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, (uint64_t)ntot, scan_scratch.p, ctr);
                     uint32_t two[2];
-                    readback(two, counters.p, 8);
+                    readback_on(ln, two, ctr, 8);
                     nNew = two[0];
                     if (two[1] == 0) break;
                     // contacts were still waiting on predecessors: the re-test above saw incomplete
                     // versions; run further rounds and re-test again
                     if (round > 6 + nH) throw std::runtime_error("psim: internal: contact schedule stalled");
                     run_rounds(6);
-                    be::launch(st, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outst.p, cbody.p, dseg.p,
-                                                             counters.p + 1});
+                    be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 1});
                 }
                 if (nNew > ccap) {
                     // growing reallocates every contact buffer: restart the whole sweep
-                    be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
-                    ensure_contact_capacity(nNew);
-                    collision_sweep(sweep);
+                    be::launch(ln.s, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+                    be::sync(ln.s);
+                    ensure_contact_capacity(ln, nNew);
+                    n_candidates -= cand;
+                    sweep_positions(ln, sweep);
                     return;
                 }
                 if (nNew > 0) {
                     r.out_keys = hn[0].p; r.write_pass = 1;
                     rp.carry.out_keys = hn[0].p; rp.carry.write_pass = 1;
-                    be::launch(st, ntot, rp);
+                    be::launch(ln.s, ntot, rp);
                 }
             }
             // H' == H?  Both are duplicate-free, so equal length + every new key found in the
             // (sorted) hypothesis means equal sets; the new list is only sorted if it is needed.
             bool same = (nNew == nH);
             if (same) {
-                be::dev_memset(st, counters.p, 0, 4);
-                be::launch(st, nNew, AllFound{(int64_t)nNew, hn[0].p, H, (int64_t)nH, counters.p});
-                same = read_u32(counters.p) == 0;
+                be::dev_memset(ln.s, ctr, 0, 4);
+                be::launch(ln.s, nNew, AllFound{(int64_t)nNew, hn[0].p, H, (int64_t)nH, ctr});
+                same = read_u32(ln, ctr) == 0;
             }
             if (same) break;
             uint64_t* kn[2] = {hn[0].p, hn[1].p};
-            hn_which = be::radix_sort_pairs<uint64_t>(st, kn, nullptr, nNew, 0, key_bits, sort_tmp.p);
-            be::launch(st, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+            hn_which = be::radix_sort_pairs<uint64_t>(ln.s, kn, nullptr, nNew, 0, key_bits, ln.sort_tmp->p);
+            be::launch(ln.s, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
             hc[0].swap(hn[hn_which]);       // the sorted new list becomes the hypothesis (same capacity)
             H = hc[0].p;
             nH = nNew;
             if (nH == 0) return;
         }
-        // ---- converged: totals, log, write-back
+        // ---- settled: positions written back, list of slots touched for the first time
+        pcount.ensure(2 * (size_t)nH); poffs.ensure(2 * (size_t)nH);
+        ContactFinalizePositions f;
+        f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outp.p; f.body = cbody.p;
+        f.pos = pos.p; f.moved = moved.p; f.newly = pcount.p;
+        be::launch(ln.s, 2ll * nH, f);
+        be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, 2ull * nH, scan_scratch.p, ctr + 5);
+        be::launch(ln.s, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
+        // (ContactFinalizePositions has already marked every touched slot clean again)
+        n_moved += read_u32(ln, ctr + 5);
+        settled_contacts = nH; settled_rounds = round; settled_adj = adjs;
+    }
+
+    // velocity half of the sweep whose position half ran last (main stream)
+    void sweep_velocities(int sweep)
+    {
+        (void)sweep;
+        const uint32_t nH = settled_contacts;
+        if (nH == 0) return;
+        for (uint32_t r = 1; r <= settled_rounds; ++r) {
+            ContactVelocity v;
+            v.n = nH; v.hsi = hsi.p; v.hsj = hsj.p; v.prev = prevl.p; v.done = done.p; v.round = r; v.out = outv.p;
+            v.geo = cgeo.p; v.vals = cvals.p; v.body = cbody.p; v.vel = vel.p; v.temp = temp.p; v.mass = mass.p;
+            v.restitution = cfg.restitution;
+            be::launch(st, nH, v);
+        }
+        // ---- totals, log, write-back
         size_t log_cap = 0;
         if (cfg.debug) {
             log_cap = (size_t)log_n + nH;
@@ -656,21 +765,16 @@ public:
         cl.sum_pe = sum_pe.p; cl.sum_ke = sum_ke.p; cl.sum_heat = sum_heat.p;
         be::launch(st, nH, cl);
         be::reduce3_sum_f64(st, sum_pe.p, sum_ke.p, sum_heat.p, nH, red_tmp.p, red_out.p);
-        pcount.ensure(2 * (size_t)nH); poffs.ensure(2 * (size_t)nH);
-        ContactFinalize f;
-        f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outst.p; f.body = cbody.p;
-        f.pos = pos.p; f.vel = vel.p; f.temp = temp.p; f.moved = moved.p; f.newly = pcount.p;
+        ContactFinalizeVelocities f;
+        f.n_adj = 2ll * nH; f.adj = settled_adj; f.hsi = hsi.p; f.out = outv.p; f.body = cbody.p; f.vel = vel.p;
+        f.temp = temp.p;
         be::launch(st, 2ll * nH, f);
-        be::exclusive_scan_u32(st, pcount.p, poffs.p, 2ull * nH, scan_tmp.p, counters.p + 5);
-        be::launch(st, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
-        // (ContactFinalize has already marked every touched slot clean again)
-        struct { double t[3]; uint32_t newly_moved; } back;
-        readback2(&back, red_out.p, 24, counters.p + 5, 4);
-        const double* t = back.t;
-        n_moved += back.newly_moved;
+        double t[3];
+        readback(t, red_out.p, 24);
         coll_totals[0] += t[0]; coll_totals[1] += t[1]; coll_totals[2] += t[2];
         n_contacts += nH;
         if (cfg.debug) log_n += nH;
+        settled_contacts = 0;
     }
 
     // particle_system.py:476-498 + :555-557.  Slots [lo, hi) only; with temp_slots the
@@ -708,43 +812,50 @@ public:
                n_coincident == 0 && n > 0;
     }
 
-    // Fills cdelta (index space) with the conduction temperature changes; the caller
-    // applies T = (T + delta) * cooling in its next streaming pass (walls_and_flags).
-    void conduction_sparse()
-    {
-        conduction_sparse_pairs();
-        if (cfg.debug) {
-            delta_dbg.ensure((size_t)n);
-            be::copy_d2d(st, delta_dbg.p, cdelta.p, (size_t)n * 8);
-        }
-    }
-    void conduction_sparse_pairs()
+    // Conduction around the touched slots.  The pair list depends on positions only and is
+    // built (on the given lane) as soon as the last sweep's positions are settled;
+    // conduction_sparse_apply() then fills cdelta (index space) from the post-collision
+    // temperatures, and the caller applies T = (T + delta) * cooling in its next streaming
+    // pass (walls_and_flags).
+    void conduction_sparse_pairs(const Lane& ln)
     {
         size_t c = (size_t)n;
         GridView g = grid_view();
         cdelta.ensure(c);
-        be::dev_memset(st, cdelta.p, 0, c * 8);
+        be::dev_memset(ln.s, cdelta.p, 0, c * 8);
+        cond_ne = 0;
+        cond_pairs_ready = true;
         if (n_moved == 0) return;
         int64_t nt = 10ll * n_moved;
-        pcount.ensure((size_t)nt); poffs.ensure((size_t)nt); scan_tmp.ensure_zero(st, be::scan_temp_words((uint64_t)nt));
+        pcount.ensure((size_t)nt); poffs.ensure((size_t)nt);
+        ln.scan_tmp->ensure_zero(ln.s, be::scan_temp_words((uint64_t)nt));
         ConductionPairs k;
         k.n_moved = n_moved; k.g = g; k.list = moved_list.p; k.moved = moved.p; k.counts = pcount.p; k.offsets = poffs.p;
         k.entries = nullptr; k.write_pass = 0;
-        be::launch(st, nt, k);
-        be::exclusive_scan_u32(st, pcount.p, poffs.p, (uint64_t)nt, scan_tmp.p, counters.p);
-        uint32_t ne = read_u32(counters.p);
+        be::launch(ln.s, nt, k);
+        be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, (uint64_t)nt, ln.scan_tmp->p, ln.ctr);
+        uint32_t ne = read_u32(ln, ln.ctr);
         if (ne == 0) return;
         cond_entries[0].ensure(ne); cond_entries[1].ensure(ne);
-        sort_tmp.ensure(be::sort_temp_words(ne));
+        ln.sort_tmp->ensure(be::sort_temp_words(ne));
         k.entries = cond_entries[0].p; k.write_pass = 1;
-        be::launch(st, nt, k);
+        be::launch(ln.s, nt, k);
         uint64_t* ke[2] = {cond_entries[0].p, cond_entries[1].p};
         int bits = 32 + ceil_log2_u64((uint64_t)n + 1);
         // targets in ascending slot order; a stable sort on the target field alone keeps the
         // sources of one target in the (fixed) order the pairs were written
-        int se = be::radix_sort_pairs<uint64_t>(st, ke, nullptr, ne, 32, bits, sort_tmp.p);
-        be::launch(st, ne, ConductionApply{(int64_t)ne, cond_entries[se].p, cbody.p, temp.p, mass.p, cfg.heat_coeff,
-                                           cdelta.p});
+        cond_sorted = be::radix_sort_pairs<uint64_t>(ln.s, ke, nullptr, ne, 32, bits, ln.sort_tmp->p);
+        cond_ne = ne;
+    }
+    void conduction_sparse_apply()
+    {
+        if (cond_ne > 0)
+            be::launch(st, cond_ne, ConductionApply{(int64_t)cond_ne, cond_entries[cond_sorted].p, cbody.p, temp.p, mass.p,
+                                                    cfg.heat_coeff, cdelta.p});
+        if (cfg.debug) {
+            delta_dbg.ensure((size_t)n);
+            be::copy_d2d(st, delta_dbg.p, cdelta.p, (size_t)n * 8);
+        }
     }
 
     // particle_system.py:500-516 and the explosion test of :658
@@ -844,13 +955,15 @@ public:
         be::sync(st);
     }
 
-    // Grid build and the first contact sweep's count pass on the side stream; released when
-    // the tree is built, so that it shares the device with the walk (FP64-bound) and not with
-    // the tree build (memory-bound like itself).  Joined by join_side_work().
+    // Grid build and the position half of the collision stage on the side stream.  They are
+    // released when the tree is built, so that they share the device with the walk
+    // (FP64-bound) and not with the tree build (memory-bound like themselves).  Joined by
+    // join_side_work().
     bool side_running = false;
     // mark_side_release() is called where the side work may start (tree built), then the walk
-    // is launched, and only then is the side work submitted: its dozen launches would otherwise
-    // sit between the tree build and the walk on the host's submission path.
+    // and the kick are launched, and only then is the side work submitted: its launches would
+    // otherwise sit between the tree build and the walk on the host's submission path, and
+    // the position half waits for small readbacks.
     void mark_side_release() { be::event_record(ev_drift, st); }
     void start_side_work()
     {
@@ -860,23 +973,48 @@ public:
         be::event_record(ev_side, st2);
         side_running = true;
     }
+    // position half of the collision stage, on the side stream when there is one
+    void settle_positions(bool after_join = false)
+    {
+        if (!(cfg.stage_mask & kStageCollisions) || positions_settled) return;
+        if (side_running && !positions_under_walk() && !after_join) return;   // the caller joins first
+        if (side_running) {
+            collisions_positions(side_lane());
+            be::event_record(ev_side, st2);
+        } else {
+            collisions_positions(main_lane());
+        }
+    }
     void join_side_work()
     {
         if (side_running) be::stream_wait(st, ev_side);
         side_running = false;
     }
+    void begin_step()
+    {
+        n_exploded = 0;
+        last_exploded.clear();
+        moved_valid = false;
+        positions_settled = false;
+        cond_pairs_ready = false;
+        cond_ne = 0;
+    }
+    void no_collisions()
+    {
+        coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0;
+        n_candidates = n_contacts = 0; log_n = 0;
+    }
 
     // particle_system.py:518-563
     void step()
     {
-        n_exploded = 0;
-        last_exploded.clear();
+        begin_step();
         timer.mark(st, 0);
         keys_and_drift(true);
         timer.mark(st, 1);
-        // The grid build and the first contact sweep's count pass are memory-bound and depend
-        // only on the drifted positions: they run on a side stream underneath the tree build
-        // and the FP64-bound walk, and are joined before the collision stage.
+        // The grid build and the position half of the collision stage depend only on the
+        // drifted positions: they run on a side stream underneath the FP64-bound walk and
+        // are joined before the velocity half.
         const bool side = cfg.overlap != 0 && n > 0;
         if (!side) build_grid();
         timer.mark(st, 2);
@@ -885,17 +1023,18 @@ public:
         if (side) mark_side_release();
         gravity(acc2.p);
         timer.mark(st, 4);
-        if (side) start_side_work();
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
+        if (side) start_side_work();
+        settle_positions();
         join_side_work();
+        settle_positions(true);
         timer.mark(st, 5);
-        moved_valid = false;
-        if (cfg.stage_mask & kStageCollisions) collisions();
-        else { coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0; n_candidates = n_contacts = 0; log_n = 0; }
+        if (cfg.stage_mask & kStageCollisions) collisions_velocities();
+        else no_collisions();
         timer.mark(st, 6);
         bool sparse = sparse_conduction_possible();
-        if (sparse) conduction_sparse(); else conduction_and_cooling();
+        if (sparse) conduction_sparse_apply(); else conduction_and_cooling();
         timer.mark(st, 7);
         uint32_t nb = walls_and_flags(sparse);
         if (nb > 0) explosions(nb);
@@ -908,8 +1047,8 @@ public:
     // grid slots and their outputs are all-gathered by the caller between stages.
     void stage_build()
     {
-        n_exploded = 0;
-        last_exploded.clear();
+        begin_step();
+        sharded_step = true;
         timer.mark(st, 0);
         keys_and_drift(true);
         timer.mark(st, 1);
@@ -928,17 +1067,24 @@ public:
         timer.mark(st, 4);
         if (side) start_side_work();
     }
+    // Optional, between stage_gravity and stage_kick_collide: the position half of the
+    // collision stage.  It waits for small readbacks of its own stream, so a caller that
+    // has an exchange of accelerations to do starts that exchange first and calls this
+    // while it is in flight.  Without the call, stage_kick_collide does the work itself.
+    void stage_settle_positions() { settle_positions(); }
     void stage_kick_collide(const vec2* acc_sorted)
     {
         be::launch(st, n, ScatterSorted{n, perm[sorted_key].p, acc_sorted, acc2.p});
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
+        settle_positions();
         join_side_work();
+        settle_positions(true);
         timer.mark(st, 5);
-        moved_valid = false;
-        if (cfg.stage_mask & kStageCollisions) collisions();
-        else { coll_totals[0] = coll_totals[1] = coll_totals[2] = 0.0; n_candidates = n_contacts = 0; log_n = 0; }
+        if (cfg.stage_mask & kStageCollisions) collisions_velocities();
+        else no_collisions();
         timer.mark(st, 6);
+        sharded_step = false;
     }
     // When conduction can run around the touched slots only it is cheap and every rank does
     // all of it in stage_finish (this call then leaves temp_slots alone); otherwise the full
@@ -954,7 +1100,7 @@ public:
         bool cond = (cfg.stage_mask & kStageConduction) != 0;
         bool cool = (cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0;
         bool sparse = sparse_conduction_possible();
-        if (sparse) conduction_sparse();
+        if (sparse) conduction_sparse_apply();
         else if (n > 0 && cond) be::launch(st, n, ScatterSlots{n, cbody.p, temp_slots, temp.p});
         else if (n > 0 && cool) be::launch(st, n, Cooling{n, temp.p, 1.0 - cfg.damping});
         uint32_t nb = walls_and_flags(sparse);

@@ -63,10 +63,11 @@ enum StageBits : int32_t {
     kStageAll = 31,
 };
 
-// per-contact record produced by the collision solver
-struct BodyState {
-    vec2 pos, vel;
+// per-contact, per-side record of the collision solver's velocity pass
+struct alignas(32) VelState {
+    vec2 vel;
     double temp;
+    double unused;
 };
 
 }  // namespace psim

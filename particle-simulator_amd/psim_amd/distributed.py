@@ -56,13 +56,14 @@ class ShardedParticleSystem(ParticleSystem):
         self._acc = torch.zeros((per * self._world, 2), dtype=torch.float64, device=self._tdev)
         self._tmp = torch.zeros((per * self._world,), dtype=torch.float64, device=self._tdev)
 
-    def _gather(self, buf, per):
-        """in-place all-gather of the ranks' equal shards of buf[: per * world]"""
+    def _gather(self, buf, per, async_op=False):
+        """in-place all-gather of the ranks' equal shards of buf[: per * world];
+        with async_op the collective is only started and its handle returned"""
         if self._world == 1:
-            return
+            return None
         flat = buf[: per * self._world]
         mine = flat[self._rank * per:(self._rank + 1) * per]
-        dist.all_gather_into_tensor(flat, mine.clone(), group=self._group)
+        return dist.all_gather_into_tensor(flat, mine.clone(), group=self._group, async_op=async_op)
 
     def update(self, steps: int = 1):
         L, ctx = self._lib, self._ctx
@@ -71,8 +72,15 @@ class ShardedParticleSystem(ParticleSystem):
             _capi.check(L, L.psim_stage_build(ctx))
             n = int(L.psim_num_particles(ctx))
             lo, hi, per = shard_range(n, self._rank, self._world)
+            # The walk is only submitted here (to the device's default stream, which is
+            # also PyTorch's); the exchange is started behind it, and while both are in
+            # flight the half of the contact solver that needs no velocities runs on the
+            # library's second stream.
             _capi.check(L, L.psim_stage_gravity(ctx, lo, hi, ctypes.c_void_p(self._acc.data_ptr())))
-            self._gather(self._acc, per)
+            work = self._gather(self._acc, per, async_op=True)
+            _capi.check(L, L.psim_stage_settle_positions(ctx))
+            if work is not None:
+                work.wait()
             if self._tdev.type == "cuda":
                 torch.cuda.current_stream().synchronize()
             _capi.check(L, L.psim_stage_kick_collide(ctx, ctypes.c_void_p(self._acc.data_ptr())))
