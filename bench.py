@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--walk-mode", type=int, default=0)
     ap.add_argument("--library", default=None, help="alternative build of libpsim_hip.so (kernel experiments)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="every stage on one stream (kernel timings without the side stream's contention)")
     ap.add_argument("--brute", type=int, default=0,
                     help="also time the all-pairs cross-check kernel on this many particles")
     args = ap.parse_args()
@@ -132,7 +134,8 @@ def main():
                                    stage_mask=mask, walk_mode=args.walk_mode, state=state)
     else:
         ps = ParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds, device=local_rank,
-                            stage_mask=mask, walk_mode=args.walk_mode, state=state, library=args.library)
+                            stage_mask=mask, walk_mode=args.walk_mode, state=state, library=args.library,
+                            overlap=not args.no_overlap)
     ps._calculate_gravity()
     for _ in range(args.warmup):
         ps.update()

@@ -209,10 +209,12 @@ inline uint32_t* lookback_fault_word()
 
 // ------------------------------------------------------------------ exclusive scan (u32)
 constexpr int kScanItems = 16;
-constexpr int kScanThreads = 256;    // small workgroups: placeable next to a walk that holds most wave slots
-constexpr int kScanTile = kScanThreads * kScanItems;
+// Workgroups of 1024 lanes, or of 256 for scans submitted next to a walk that holds most wave
+// slots (a 1024-lane workgroup needs four free slots on every SIMD of one CU at once).
+constexpr int kScanThreadsSmall = 256;
+constexpr int kScanTileSmall = kScanThreadsSmall * kScanItems;
 
-// One launch for any length: each 256-lane workgroup takes the next 4096-item tile
+// One launch for any length: each workgroup takes the next tile of 16 items per lane
 // (numbered by an atomic counter), scans it, publishes the tile's sum and finds the
 // sum of everything before it by looking back over its predecessors' status words
 // (64 at a time, one per lane of the first wave): a predecessor shows either its own
@@ -221,10 +223,12 @@ constexpr int kScanTile = kScanThreads * kScanItems;
 // before its first use.
 constexpr uint64_t kScanLocal = 1ull << 62, kScanInclusive = 2ull << 62, kScanValue = (1ull << 62) - 1;
 
+template <int kScanThreads>
 __global__ void __launch_bounds__(kScanThreads) scan_lookback_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
-                                                            uint32_t ntiles, uint32_t* temp, uint32_t* total_out,
-                                                            uint32_t* fault)
+                                                                     uint32_t ntiles, uint32_t* temp, uint32_t* total_out,
+                                                                     uint32_t* fault)
 {
+    constexpr int kScanTile = kScanThreads * kScanItems;
     __shared__ uint32_t wsum[17];
     __shared__ uint32_t s_tile, s_failed;
     __shared__ uint64_t s_before;
@@ -335,10 +339,12 @@ __global__ void __launch_bounds__(kScanThreads) scan_lookback_kernel(const uint3
 }
 
 // whole scan in one workgroup (n <= kScanSmall), tile after tile with a running total
-constexpr uint32_t kScanSmall = 4u * kScanTile;
+constexpr uint32_t kScanSmall = 4u * kScanTileSmall;
+template <int kScanThreads>
 __global__ void __launch_bounds__(kScanThreads) scan_small_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
                                                                   uint32_t* total_out)
 {
+    constexpr int kScanTile = kScanThreads * kScanItems;
     __shared__ uint32_t wsum[17];
     uint32_t before = 0;
     for (uint32_t tile0 = 0; tile0 < n; tile0 += kScanTile) {
@@ -356,23 +362,34 @@ __global__ void __launch_bounds__(kScanThreads) scan_small_kernel(const uint32_t
     if (threadIdx.x == 0 && total_out) *total_out = before;
 }
 
-inline size_t scan_temp_words(uint64_t n) { return 16 + 2 * (size_t)((n + kScanTile - 1) / kScanTile) + 2; }
+inline size_t scan_temp_words(uint64_t n) { return 16 + 2 * (size_t)((n + kScanTileSmall - 1) / kScanTileSmall) + 2; }
 
 // out may alias in.  temp: scan_temp_words(n) words, ZERO before its first use (each scan
 // leaves it zero again).  total_out: device word or null.
 inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t* temp,
-                               uint32_t* total_out)
+                               uint32_t* total_out, bool small_groups = false)
 {
     if (n == 0) { if (total_out) dev_memset(st, total_out, 0, 4); return; }
     if (n > 0xfffffff0ull) throw std::runtime_error("exclusive_scan_u32: too many items");
     if (n <= kScanSmall) {
-        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(kScanThreads), 0, st, in, out, (uint32_t)n, total_out);
+        if (small_groups)
+            hipLaunchKernelGGL(scan_small_kernel<kScanThreadsSmall>, dim3(1), dim3(kScanThreadsSmall), 0, st, in, out,
+                               (uint32_t)n, total_out);
+        else
+            hipLaunchKernelGGL(scan_small_kernel<1024>, dim3(1), dim3(1024), 0, st, in, out, (uint32_t)n, total_out);
         PSIM_HIP(hipGetLastError());
         return;
     }
-    uint32_t nb = (uint32_t)((n + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(scan_lookback_kernel, dim3(nb), dim3(kScanThreads), 0, st, in, out, (uint32_t)n, nb, temp, total_out,
-                       lookback_fault_word());
+    if (small_groups) {
+        uint32_t nb = (uint32_t)((n + kScanTileSmall - 1) / kScanTileSmall);
+        hipLaunchKernelGGL(scan_lookback_kernel<kScanThreadsSmall>, dim3(nb), dim3(kScanThreadsSmall), 0, st, in, out,
+                           (uint32_t)n, nb, temp, total_out, lookback_fault_word());
+    } else {
+        const uint32_t tile = 1024u * kScanItems;
+        uint32_t nb = (uint32_t)((n + tile - 1) / tile);
+        hipLaunchKernelGGL(scan_lookback_kernel<1024>, dim3(nb), dim3(1024), 0, st, in, out, (uint32_t)n, nb, temp,
+                           total_out, lookback_fault_word());
+    }
     PSIM_HIP(hipGetLastError());
 }
 

@@ -541,8 +541,8 @@ int psim_selftest(int device_ordinal, int64_t n, uint64_t seed)
         uint32_t run = 0;
         for (size_t i = 0; i < c; ++i) { if (gs[i] != run) throw std::runtime_error("selftest: scan mismatch at " + std::to_string(i)); run += hs[i]; }
         if (gtot != run) throw std::runtime_error("selftest: scan total mismatch");
-        // again, in place, on the scratch the first scan left behind
-        be::exclusive_scan_u32(st, a0.p, a0.p, (uint64_t)n, stmp.p, tot.p);
+        // again, in place, on the scratch the first scan left behind, with the small workgroups
+        be::exclusive_scan_u32(st, a0.p, a0.p, (uint64_t)n, stmp.p, tot.p, true);
         be::copy_d2h(st, gs.data(), a0.p, c * 4);
         be::copy_d2h(st, &gtot, tot.p, 4);
         be::sync(st);

@@ -775,50 +775,58 @@ struct ContactDetect {
     // Every unordered candidate pair is examined once: in-cell pairs from the earlier
     // slot, cross-cell pairs from the cell that has the other one among its four
     // "forward" neighbours (E, SW, S, SE).  A contact is keyed from its lower-index
-    // particle, whichever side found it.
+    // particle, whichever side found it.  Cells are row-major, so the candidates of a
+    // slot are two runs of consecutive slots: the rest of its own cell followed by the E
+    // cell, and the SW, S, SE cells; the records of a run are fetched four at a time.
     template <bool WRITE>
     PSIM_HD PSIM_FORCEINLINE void run(uint32_t k) const
     {
-        const CellBody me = g.body[k];
-        uint32_t p = me.idx, c = me.cell;
-        uint32_t a = k - (uint32_t)g.offsets[c];
-        vec2 P = body_pos(me);
-        int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
+        const CellBody* PSIM_RESTRICT body = g.body;
+        const CellBody me = body[k];
+        const uint32_t c = me.cell;
+        const double px = me.x, py = me.y;
+        const int32_t mr = me.r;
+        const int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
+        const bool east = cx + 1 < g.gw, west = cx > 0, south = cy + 1 < g.gh;
+        const int32_t a_hi = g.offsets[c + (east ? 2u : 1u)];
+        int32_t b_lo = 0, b_hi = 0;
+        if (south) {
+            const uint32_t s = c + (uint32_t)g.gw;
+            b_lo = g.offsets[s - (west ? 1u : 0u)];
+            b_hi = g.offsets[s + (east ? 2u : 1u)];
+        }
         uint32_t ncand = 0, found = 0;
-        uint32_t at = WRITE ? offsets[k] : 0u;
-        for (int32_t b = (int32_t)k + 1; b < g.offsets[c + 1]; ++b) {
-            const CellBody o = g.body[b];
+        const uint32_t at = WRITE ? offsets[k] : 0u;
+        auto visit = [&](const CellBody& o, int32_t b) {
             ++ncand;
-            if (in_contact(P, body_pos(o), me.r, o.r)) {
-                if (WRITE) out_keys[at + found] = make_pair_key(g, c, 0, a, (uint32_t)b - (uint32_t)g.offsets[c]);
+            // particle_system.py:210-217; the squared distance does not depend on which
+            // of the two is "i" (the differences only change sign)
+            double dx = o.x - px, dy = o.y - py;
+            double d2 = dx * dx + dy * dy;
+            double md = (double)(mr + o.r);
+            if (d2 < md * md && d2 > 0) {
+                if (WRITE) out_keys[at + found] = pair_key(g, k, (uint32_t)b);
                 else if (found == 0) first_pair[k] = ((uint64_t)k << 32) | (uint64_t)(uint32_t)b;
                 ++found;
-            } else if (!WRITE && coincident(P, body_pos(o))) {
+            } else if (!WRITE && d2 == 0) {
                 aggregated_inc(coincident_counter);
             }
-        }
-        for (int f = 0; f < 4; ++f) {
-            int dx = (f == 0) ? 1 : f - 2, dy = (f == 0) ? 0 : 1;
-            int nx = cx + dx, ny = cy + dy;
-            if (nx < 0 || nx >= g.gw || ny >= g.gh) continue;
-            uint32_t nc = (uint32_t)(ny * g.gw + nx);
-            int32_t o0 = g.offsets[nc];
-            for (int32_t b = o0; b < g.offsets[nc + 1]; ++b) {
-                const CellBody o = g.body[b];
-                ++ncand;
-                bool lower = p < o.idx;
-                bool hit = lower ? in_contact(P, body_pos(o), me.r, o.r) : in_contact(body_pos(o), P, o.r, me.r);
-                if (hit) {
-                    if (WRITE)
-                        out_keys[at + found] = lower ? make_pair_key(g, c, neighbour_phase(dy, dx), a, (uint32_t)(b - o0))
-                                                     : make_pair_key(g, nc, neighbour_phase(-dy, -dx), (uint32_t)(b - o0), a);
-                    else if (found == 0) first_pair[k] = ((uint64_t)k << 32) | (uint64_t)(uint32_t)b;
-                    ++found;
-                } else if (!WRITE && coincident(P, body_pos(o))) {
-                    aggregated_inc(coincident_counter);
-                }
+        };
+        auto sweep = [&](int32_t lo, int32_t hi) {
+            for (int32_t b = lo; b < hi; b += 4) {
+                const int32_t last = hi - 1;
+                const CellBody o0 = body[b];
+                const CellBody o1 = body[b + 1 < hi ? b + 1 : last];
+                const CellBody o2 = body[b + 2 < hi ? b + 2 : last];
+                const CellBody o3 = body[b + 3 < hi ? b + 3 : last];
+                visit(o0, b);
+                if (b + 1 < hi) visit(o1, b + 1);
+                if (b + 2 < hi) visit(o2, b + 2);
+                if (b + 3 < hi) visit(o3, b + 3);
             }
-        }
+        };
+        sweep((int32_t)k + 1, a_hi);
+        sweep(b_lo, b_hi);
         if (!WRITE) {
             counts[k] = found;
             if (cand_counter && ncand) atomic_inc_u32(cand_counter, ncand);

@@ -189,9 +189,10 @@ public:
         DevBuf<uint32_t>* scan_tmp;
         uint32_t* ctr;             // 16 words
         be::Mailbox* box;
+        bool small_groups;         // its scans use workgroups that fit next to the walk
     };
-    Lane main_lane() { return Lane{st, &sort_tmp, &scan_tmp, counters.p, &mailbox}; }
-    Lane side_lane() { return Lane{st2, &sort_tmp2, &scan_tmp2, counters2.p, &mailbox2}; }
+    Lane main_lane() { return Lane{st, &sort_tmp, &scan_tmp, counters.p, &mailbox, false}; }
+    Lane side_lane() { return Lane{st2, &sort_tmp2, &scan_tmp2, counters2.p, &mailbox2, true}; }
     // what the position half leaves for the velocity half of the same sweep
     uint32_t settled_contacts = 0, settled_rounds = 0;
     uint64_t* settled_adj = nullptr;
@@ -393,7 +394,7 @@ public:
 
     // count pass of the first collision sweep (positions do not change between the drift and
     // the collision stage): per-slot contact counts, their scan, and the largest cell population
-    void detect_count(be::Stream s, DevBuf<uint32_t>& scan_scratch, uint32_t* ctr)
+    void detect_count(be::Stream s, DevBuf<uint32_t>& scan_scratch, uint32_t* ctr, bool small_groups)
     {
         size_t c = (size_t)n;
         const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
@@ -405,7 +406,7 @@ public:
         d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? ctr + 1 : nullptr;
         d.coincident_counter = ctr + 3;
         be::launch(s, n, d);
-        be::exclusive_scan_u32(s, pcount.p, poffs.p, (uint64_t)n, scan_scratch.p, ctr);
+        be::exclusive_scan_u32(s, pcount.p, poffs.p, (uint64_t)n, scan_scratch.p, ctr, small_groups);
         int64_t cwaves = (cells + 63) / 64;
         tmp32.ensure((size_t)cwaves + (size_t)(cwaves + 63) / 64 + 64);
         be::launch(s, cwaves * 64, WaveMaxOccupancy{cells, offsets.p, tmp32.p});
@@ -597,7 +598,7 @@ public:
                 dctr = counters2.p;         // already computed on the side stream (this lane, or joined by the caller)
                 predetected = false;
             } else {
-                detect_count(ln.s, scan_scratch, ctr);
+                detect_count(ln.s, scan_scratch, ctr, ln.small_groups);
             }
             ContactDetect d;
             d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
@@ -674,7 +675,7 @@ public:
                 rp.nt = nt; rp.n0 = n0;
                 for (;;) {
                     be::launch(ln.s, ntot + nH, rp);
-                    be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, (uint64_t)ntot, scan_scratch.p, ctr);
+                    be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, (uint64_t)ntot, scan_scratch.p, ctr, ln.small_groups);
                     uint32_t two[2];
                     readback_on(ln, two, ctr, 8);
                     nNew = two[0];
@@ -723,7 +724,7 @@ public:
         f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outp.p; f.body = cbody.p;
         f.pos = pos.p; f.moved = moved.p; f.newly = pcount.p;
         be::launch(ln.s, 2ll * nH, f);
-        be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, 2ull * nH, scan_scratch.p, ctr + 5);
+        be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, 2ull * nH, scan_scratch.p, ctr + 5, ln.small_groups);
         be::launch(ln.s, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
         // (ContactFinalizePositions has already marked every touched slot clean again)
         n_moved += read_u32(ln, ctr + 5);
@@ -833,7 +834,7 @@ public:
         k.n_moved = n_moved; k.g = g; k.list = moved_list.p; k.moved = moved.p; k.counts = pcount.p; k.offsets = poffs.p;
         k.entries = nullptr; k.write_pass = 0;
         be::launch(ln.s, nt, k);
-        be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, (uint64_t)nt, ln.scan_tmp->p, ln.ctr);
+        be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, (uint64_t)nt, ln.scan_tmp->p, ln.ctr, ln.small_groups);
         uint32_t ne = read_u32(ln, ln.ctr);
         if (ne == 0) return;
         cond_entries[0].ensure(ne); cond_entries[1].ensure(ne);
@@ -969,7 +970,7 @@ public:
     {
         be::stream_wait(st2, ev_drift);
         build_grid(st2, sort_tmp2);
-        if (cfg.stage_mask & kStageCollisions) { detect_count(st2, scan_tmp2, counters2.p); predetected = true; }
+        if (cfg.stage_mask & kStageCollisions) { detect_count(st2, scan_tmp2, counters2.p, true); predetected = true; }
         be::event_record(ev_side, st2);
         side_running = true;
     }

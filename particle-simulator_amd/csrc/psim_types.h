@@ -7,10 +7,12 @@
 // Test-only build: kernel bodies run as host loops (tests/hostloop).  Never shipped.
 #define PSIM_HD
 #define PSIM_FORCEINLINE inline
+#define PSIM_RESTRICT __restrict__
 #else
 #include <hip/hip_runtime.h>
 #define PSIM_HD __host__ __device__
 #define PSIM_FORCEINLINE __forceinline__
+#define PSIM_RESTRICT __restrict__
 #endif
 
 namespace psim {

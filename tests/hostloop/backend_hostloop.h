@@ -53,7 +53,8 @@ inline void launch(Stream, int64_t n, const F& f)
 }
 
 inline size_t scan_temp_words(uint64_t) { return 1; }
-inline void exclusive_scan_u32(Stream, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t*, uint32_t* total_out)
+inline void exclusive_scan_u32(Stream, const uint32_t* in, uint32_t* out, uint64_t n, uint32_t*, uint32_t* total_out,
+                               bool = false)
 {
     uint32_t run = 0;
     for (uint64_t i = 0; i < n; ++i) { uint32_t t = in[i]; out[i] = run; run += t; }
