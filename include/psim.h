@@ -159,6 +159,14 @@ int64_t psim_explosion_events(psim_context* ctx, psim_explosion_event* buf, int6
  * summed over 64-lane waves, [3] trips in which some lane accepted */
 int psim_walk_counts(psim_context* ctx, int64_t out[4]);
 
+/* timing hook for benchmarks: average duration in milliseconds of `reps` launches of the
+ * default walk kernel on the current tree with nothing else on the device (results go to
+ * a scratch buffer).  slots_per_simd = 0 launches the whole grid at once; a value up to 8
+ * keeps that many waves per SIMD resident and has them take chunks of targets from a
+ * counter, as psim_step does when it runs other work next to the walk.  No counterpart in
+ * the reference. */
+int psim_time_walk(psim_context* ctx, int32_t reps, double slots_per_simd, double* ms_avg);
+
 /* cross-check (no counterpart in the reference): all-pairs softened gravity of the
  * current state with the force law of particle_system.py:86-93, O(n^2) FP64.
  * accelerations_out: host (n,2) float64.  kernel_ms (may be NULL) receives the

@@ -324,6 +324,48 @@ int psim_walk_counts(psim_context* ctx, int64_t out[4])
     PSIM_TRY(ctx && out, walk_counts_impl(ctx, out))
 }
 
+static void time_walk_impl(psim_context* ctx, int32_t reps, double slots_per_simd, double* ms_avg)
+{
+    use_device(ctx->device);
+    psim::Sim* s = ctx->sim;
+    *ms_avg = 0.0;
+    if (!s->tree_valid || s->n == 0) throw std::runtime_error("psim: no tree built yet");
+    if (reps < 1 || reps > 1000 || !(slots_per_simd >= 0.0) || slots_per_simd > 8.0)
+        throw std::invalid_argument("psim: bad repetition count or slot count");
+#if !defined(PSIM_HOSTLOOP)
+    uint32_t total = (uint32_t)(s->n + s->n_internal);
+    double theta2 = s->cfg.theta * s->cfg.theta;
+    psim::DevBuf<psim::vec2> scratch;
+    scratch.ensure((size_t)s->n);
+    int64_t resident = (int64_t)(psim::be::compute_units() * 4 * slots_per_simd);
+    auto once = [&]() {
+        psim::be::launch_walk_multi<2>(s->st, (int64_t)0, s->n, 0, (const psim::NodeRec*)s->rec.p, total,
+                                       (const psim::vec2*)s->spos.p, (const double*)s->smass.p,
+                                       (const uint32_t*)s->perm[s->sorted_key].p, (const double*)s->inv_mass.p, scratch.p,
+                                       s->walk_fold, (uint32_t)s->w2_cmp_bits, theta2, s->cfg.gravity_constant,
+                                       s->cfg.softening, s->walk_ctr.p, resident);
+    };
+    once();
+    hipEvent_t e0, e1;
+    PSIM_HIP(hipEventCreate(&e0));
+    PSIM_HIP(hipEventCreate(&e1));
+    PSIM_HIP(hipEventRecord(e0, s->st));
+    for (int32_t r = 0; r < reps; ++r) once();
+    PSIM_HIP(hipEventRecord(e1, s->st));
+    PSIM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PSIM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_avg = (double)ms / reps;
+#endif
+}
+
+int psim_time_walk(psim_context* ctx, int32_t reps, double slots_per_simd, double* ms_avg)
+{
+    PSIM_TRY(ctx && ms_avg, time_walk_impl(ctx, reps, slots_per_simd, ms_avg))
+}
+
 static void brute_force_impl(psim_context* ctx, double* out, double* kernel_ms)
 {
     use_device(ctx->device);

@@ -171,13 +171,13 @@ public:
     int64_t walk_resident_waves() const
     {
         static const char* e = getenv("PSIM_WALK_WAVES");
-        int per_simd = 0;
-        if (e) per_simd = atoi(e);
+        double per_simd = 0;
+        if (e) per_simd = atof(e);
         else if (cfg.overlap != 0 && n > 0) {
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
             else per_simd = (n < (8ll << 20)) ? 6 : 7;
         }
-        return per_simd > 0 ? (int64_t)be::compute_units() * 4 * per_simd : 0;
+        return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
     be::Stream st2;
     be::Event ev_drift, ev_side;

@@ -277,6 +277,13 @@ class ParticleSystem:
         self.last_walk_trips = (int(out[2]), int(out[3]))
         return int(out[0]), int(out[1])
 
+    def time_walk(self, reps=3, slots_per_simd=0.0):
+        """Average milliseconds of the default walk kernel on the current tree with the
+        device to itself (0 = whole grid at once; else that many resident waves per SIMD)."""
+        ms = ctypes.c_double(0.0)
+        _capi.check(self._lib, self._lib.psim_time_walk(self._ctx, int(reps), float(slots_per_simd), ctypes.byref(ms)))
+        return ms.value
+
     def brute_force_accelerations(self):
         """All-pairs softened gravity of the current state (O(n^2) cross-check).
         Returns (accelerations (n,2), kernel milliseconds)."""
