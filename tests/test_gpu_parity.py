@@ -9,6 +9,7 @@ import pytest
 import parity
 from conftest import load_golden
 from psim_amd import _capi
+from psim_amd.particle_system import ParticleSystem
 
 pytestmark = pytest.mark.gpu
 
@@ -103,6 +104,29 @@ def test_oracle_dense_hot_20k():
     """4x default density, hot start: contact chains and explosions"""
     sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)
     parity.run_against_oracle(20000, sim, 6, (3000, 1700), 3, HIP)
+
+
+def test_side_stream_on_and_off_give_identical_states():
+    """The grid build and the position half of the contact solver run on a second stream
+    underneath the walk (overlap=True, the default) or on the main stream (overlap=False):
+    same kernels, same order per stream, so every array must come out bit-identical."""
+    n, bounds = 300000, (24000, 12500)
+    a = ParticleSystem(n, dict(SIM), np.random.default_rng(5), bounds, library=HIP, overlap=True)
+    b = ParticleSystem(n, dict(SIM), np.random.default_rng(5), bounds, library=HIP, overlap=False)
+    for s in (a, b):
+        s._calculate_gravity()
+    for _ in range(4):
+        a.update()
+        b.update()
+        assert a.counts()["contacts"] == b.counts()["contacts"] > 0
+        for name in ("positions", "velocities", "accelerations", "temperatures"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), name
+        assert (a.pe_gain_collisions, a.ke_loss_collisions, a.heat_generated_collisions) == \
+               (b.pe_gain_collisions, b.ke_loss_collisions, b.heat_generated_collisions)
+    ms_whole, ms_resident = a.time_walk(2, 0.0), a.time_walk(2, 6.0)
+    assert 0.0 < ms_whole < 1000.0 and 0.0 < ms_resident < 1000.0
+    a.close()
+    b.close()
 
 
 def test_walk_variants_agree_and_counts():

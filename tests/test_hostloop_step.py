@@ -56,6 +56,13 @@ def test_near_coincident_knots_vs_oracle(clusters, per, spread):
     parity.run_against_oracle(n, SIM, 1, bounds, 3, HOSTLOOP, walk_mode=1, state=st)
 
 
+def test_two_collision_sweeps_hot_start_vs_oracle():
+    """collision_solver_iterations = 2 at 4x default density with a hot start: the second
+    sweep's position half follows the first sweep's velocity half (contact chains, explosions)"""
+    sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)
+    parity.run_against_oracle(2500, sim, 6, (1060, 600), 3, HOSTLOOP, walk_mode=1)
+
+
 @pytest.mark.parametrize("mask", [0, 2 | 4 | 8, 1 | 8, 31 - 2])
 def test_stage_masks_vs_oracle(mask):
     """stage switches (the reference has none; the oracle mirrors them): gravity only;
