@@ -931,6 +931,10 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 // group with its own cursor.  The K elements are requested together, so one wait covers
 // K fetches and one group's trip hides the others' latency; when the first group
 // finishes, the rest complete one after the other.
+// The kernel's scalar register count matters beyond its own occupancy: it shares every SIMD
+// with the side stream's kernels, and a build that took 83 instead of 77 SGPRs (two more
+// pointer arguments, for a velocity kick fused into the epilogue) left those kernels 1.5x
+// slower under the walk (tools/kernel_resources.py lists what every kernel allocates).
 template <int K, bool FOLD, bool WIDE>
 __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,

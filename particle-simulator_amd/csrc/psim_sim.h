@@ -146,6 +146,10 @@ public:
     // scratch
     DevBuf<uint32_t> sort_tmp, scan_tmp, counters;   // counters: 16 words
     DevBuf<uint32_t> sort_tmp2, scan_tmp2, counters2;   // scratch of the side stream
+    // What the host reads back once at the end of a step: words 0-5 the last collision sweep's
+    // totals (three doubles), word 6 the number of exploding particles.
+    DevBuf<uint32_t> step_words;
+    bool totals_pending = false;
     DevBuf<uint32_t> walk_ctr;       // chunk counter of the persistent walk (two words, zero between launches)
     // Waves the walk keeps resident (0 = one wave per chunk of targets, the whole grid at once).
     // A whole-grid walk is dispatched ahead of anything the other stream submits: that stream's
@@ -228,6 +232,7 @@ public:
         be::mailbox_create(mailbox2);
         counters.ensure(16);
         counters2.ensure(16);
+        step_words.ensure(16);
         walk_ctr.ensure_zero(st, 16);
         st2 = be::stream_create();
         ev_drift = be::event_create();
@@ -571,6 +576,7 @@ public:
             sweep_positions(ln, it);
             sweep_velocities(it);
         }
+        // (the last sweep's totals stay on the device until the step's final readback)
         moved_valid = true;
         if (sparse_conduction_possible() && !cond_pairs_ready) conduction_sparse_pairs(ln);
     }
@@ -734,7 +740,6 @@ public:
     // velocity half of the sweep whose position half ran last (main stream)
     void sweep_velocities(int sweep)
     {
-        (void)sweep;
         const uint32_t nH = settled_contacts;
         if (nH == 0) return;
         for (uint32_t r = 1; r <= settled_rounds; ++r) {
@@ -765,14 +770,20 @@ public:
         cl.log_base = log_n; cl.log_cap = (int64_t)log_cap;
         cl.sum_pe = sum_pe.p; cl.sum_ke = sum_ke.p; cl.sum_heat = sum_heat.p;
         be::launch(st, nH, cl);
-        be::reduce3_sum_f64(st, sum_pe.p, sum_ke.p, sum_heat.p, nH, red_tmp.p, red_out.p);
+        const bool last_sweep = sweep + 1 >= cfg.solver_iterations;
+        double* totals_dev = last_sweep ? reinterpret_cast<double*>(step_words.p) : red_out.p;
+        be::reduce3_sum_f64(st, sum_pe.p, sum_ke.p, sum_heat.p, nH, red_tmp.p, totals_dev);
         ContactFinalizeVelocities f;
         f.n_adj = 2ll * nH; f.adj = settled_adj; f.hsi = hsi.p; f.out = outv.p; f.body = cbody.p; f.vel = vel.p;
         f.temp = temp.p;
         be::launch(st, 2ll * nH, f);
-        double t[3];
-        readback(t, red_out.p, 24);
-        coll_totals[0] += t[0]; coll_totals[1] += t[1]; coll_totals[2] += t[2];
+        if (last_sweep) {
+            totals_pending = true;       // fetched with the explosion count (walls_and_flags)
+        } else {
+            double t[3];
+            readback(t, red_out.p, 24);
+            coll_totals[0] += t[0]; coll_totals[1] += t[1]; coll_totals[2] += t[2];
+        }
         n_contacts += nH;
         if (cfg.debug) log_n += nH;
         settled_contacts = 0;
@@ -863,22 +874,29 @@ public:
     uint32_t walls_and_flags(bool apply_delta = false)
     {
         bool w = (cfg.stage_mask & kStageWalls) != 0, f = (cfg.stage_mask & kStageExplosions) != 0;
-        if (n == 0 || (!w && !f && !apply_delta)) return 0;
+        auto fetch = [&](bool want_count) -> uint32_t {
+            // one synchronisation for the collision totals, the explosion count and the sorts' fault word
+            if (!want_count && !totals_pending) return 0;
+            struct { double t[3]; uint32_t count; } back;
+            readback(&back, step_words.p, 28, true);
+            if (totals_pending) {
+                coll_totals[0] += back.t[0]; coll_totals[1] += back.t[1]; coll_totals[2] += back.t[2];
+                totals_pending = false;
+            }
+            return want_count ? back.count : 0;
+        };
+        if (n == 0 || (!w && !f && !apply_delta)) return fetch(false);
         boom.ensure((size_t)n);
-        be::dev_memset(st, counters.p, 0, 4);
+        be::dev_memset(st, step_words.p + 6, 0, 4);
         WallsFlag k;
         k.n = n; k.pos = pos.p; k.vel = vel.p; k.radii = radii.p; k.temp = temp.p; k.W = cfg.bounds_w;
         k.H = cfg.bounds_h; k.explode_temp = cfg.explode_temp; k.do_walls = w; k.do_flag = f; k.boom = boom.p;
-        k.boom_count = counters.p;
+        k.boom_count = step_words.p + 6;
         k.delta = apply_delta ? cdelta.p : nullptr;
         k.cool_factor = 1.0 - cfg.damping;
         k.do_cool = ((cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0) ? 1 : 0;
         be::launch(st, n, k);
-        if (!f) return 0;
-        // one synchronisation for the explosion count and the sorts' fault word
-        uint32_t count = 0;
-        readback(&count, counters.p, 4, true);
-        return count;
+        return fetch(f);
     }
 
     // particle_system.py:651-730
@@ -999,6 +1017,7 @@ public:
         positions_settled = false;
         cond_pairs_ready = false;
         cond_ne = 0;
+        totals_pending = false;
     }
     void no_collisions()
     {
