@@ -104,6 +104,19 @@ int psim_step(psim_context* ctx, int64_t k_steps);
  *                            device's default stream): an exchange submitted to that stream,
  *                            or to one that waits for it, is ordered after the walk.
  *   -- all-gather acc_sorted (may be started asynchronously) --
+ *   psim_stage_detect        optional: contact detection of the first sweep for the grid
+ *                            slots [k_lo, k_hi) only (k_lo a multiple of 4) -> keys_out (device
+ *                            pointer, room for `cap` 64-bit keys).  Cells are row-major, so a
+ *                            range of slots is a slab of the domain; every rank holds all
+ *                            positions, so a slab needs no halo.  out[0] contacts found in the
+ *                            range, out[1] candidate pairs examined (counted in debug builds of
+ *                            the configuration only), out[2] pairs at squared distance zero,
+ *                            out[3] keys written (0 when cap < out[0]: call again with room).
+ *   -- all-gather the key lists --
+ *   psim_stage_settle_positions_from  as psim_stage_settle_positions, but on the gathered list
+ *                            (device pointer, n_keys keys in any order) instead of a sweep
+ *                            over all slots; candidates / coincident are the sums of out[1] /
+ *                            out[2] over the ranks
  *   psim_stage_settle_positions  optional: the half of the contact solver that needs no
  *                            velocities (contact list, pushed-apart positions), on the
  *                            library's second stream while the exchange is in flight;
@@ -117,6 +130,9 @@ int psim_step(psim_context* ctx, int64_t k_steps);
 int psim_stage_build(psim_context* ctx);
 int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* acc_sorted);
 int psim_stage_settle_positions(psim_context* ctx);
+int psim_stage_detect(psim_context* ctx, int64_t k_lo, int64_t k_hi, uint64_t* keys_out, int64_t cap, int64_t out[4]);
+int psim_stage_settle_positions_from(psim_context* ctx, const uint64_t* keys, int64_t n_keys, int64_t candidates,
+                                     int64_t coincident);
 int psim_stage_kick_collide(psim_context* ctx, const double* acc_sorted);
 int psim_stage_conduction(psim_context* ctx, int64_t k_lo, int64_t k_hi, double* temp_slots);
 int psim_stage_finish(psim_context* ctx, const double* temp_slots);

@@ -200,6 +200,23 @@ int psim_stage_settle_positions(psim_context* ctx)
     })
 }
 
+int psim_stage_detect(psim_context* ctx, int64_t k_lo, int64_t k_hi, uint64_t* keys_out, int64_t cap, int64_t out[4])
+{
+    PSIM_TRY(ctx && out && (keys_out || cap == 0) && cap >= 0, {
+        use_device(ctx->device);
+        ctx->sim->stage_detect(k_lo, k_hi, keys_out, cap, out);
+    })
+}
+
+int psim_stage_settle_positions_from(psim_context* ctx, const uint64_t* keys, int64_t n_keys, int64_t candidates,
+                                     int64_t coincident)
+{
+    PSIM_TRY(ctx, {
+        use_device(ctx->device);
+        ctx->sim->stage_settle_positions_from(keys, n_keys, candidates, coincident);
+    })
+}
+
 int psim_stage_kick_collide(psim_context* ctx, const double* acc_sorted)
 {
     PSIM_TRY(ctx && acc_sorted, {

@@ -762,7 +762,8 @@ PSIM_HD PSIM_FORCEINLINE void for_each_slot_in_cell(const GridView& g, uint32_t 
 // two slots; pass 1 writes that pair's key at its scanned offset, and only the
 // slots that found two or more redo their tests.
 struct ContactDetect {
-    int64_t n;
+    int64_t n;                 // slots [k0, k0 + n) are swept
+    uint32_t k0;
     GridView g;
     uint32_t* counts;          // pass 0: written; pass 1: read
     const uint32_t* offsets;   // pass 1: exclusive scan of counts
@@ -834,16 +835,17 @@ struct ContactDetect {
     }
     PSIM_HD void operator()(int64_t kk) const
     {
+        const uint32_t k = k0 + (uint32_t)kk;
         if (write_pass) {
-            uint32_t c = counts[kk];
+            uint32_t c = counts[k];
             if (c == 1) {
-                uint64_t fp = first_pair[kk];
-                out_keys[offsets[kk]] = pair_key(g, (uint32_t)(fp >> 32), (uint32_t)fp);
+                uint64_t fp = first_pair[k];
+                out_keys[offsets[k]] = pair_key(g, (uint32_t)(fp >> 32), (uint32_t)fp);
             } else if (c > 1) {
-                run<true>((uint32_t)kk);
+                run<true>(k);
             }
         } else {
-            run<false>((uint32_t)kk);
+            run<false>(k);
         }
     }
 };

@@ -399,19 +399,24 @@ public:
 
     // count pass of the first collision sweep (positions do not change between the drift and
     // the collision stage): per-slot contact counts, their scan, and the largest cell population
-    void detect_count(be::Stream s, DevBuf<uint32_t>& scan_scratch, uint32_t* ctr, bool small_groups)
+    // With a slot range [k_lo, k_hi) (a slab of whole grid rows when the caller cuts at cell
+    // boundaries; any cut is valid) only that range is swept and scanned: ctr[0] is then the
+    // range's contact count and offsets[] start at 0 at k_lo.  k_lo must be a multiple of 4.
+    void detect_count(be::Stream s, DevBuf<uint32_t>& scan_scratch, uint32_t* ctr, bool small_groups, int64_t k_lo = 0,
+                      int64_t k_hi = -1)
     {
         size_t c = (size_t)n;
+        if (k_hi < 0) k_hi = n;
         const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
         GridView g = grid_view();
         pcount.ensure(c); poffs.ensure(c); first_key.ensure(c); scan_scratch.ensure_zero(s, be::scan_temp_words(c));
         be::dev_memset(s, ctr, 0, 64);
         ContactDetect d;
-        d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
+        d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
         d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? ctr + 1 : nullptr;
         d.coincident_counter = ctr + 3;
-        be::launch(s, n, d);
-        be::exclusive_scan_u32(s, pcount.p, poffs.p, (uint64_t)n, scan_scratch.p, ctr, small_groups);
+        be::launch(s, k_hi - k_lo, d);
+        be::exclusive_scan_u32(s, pcount.p + k_lo, poffs.p + k_lo, (uint64_t)(k_hi - k_lo), scan_scratch.p, ctr, small_groups);
         int64_t cwaves = (cells + 63) / 64;
         tmp32.ensure((size_t)cwaves + (size_t)(cwaves + 63) / 64 + 64);
         be::launch(s, cwaves * 64, WaveMaxOccupancy{cells, offsets.p, tmp32.p});
@@ -587,6 +592,23 @@ public:
         collisions_velocities();
     }
 
+    void set_slot_bits(uint32_t max_occupancy)
+    {
+        slot_bits = ceil_log2_u64((uint64_t)max_occupancy + 1);
+        if (slot_bits < 1) slot_bits = 1;
+    }
+    int pair_key_bits() const
+    {
+        const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
+        int bits = ceil_log2_u64((uint64_t)cells) + 4 + 2 * slot_bits;
+        if (bits > 64) throw std::runtime_error("psim: grid cell population too large for the pair-key layout");
+        return bits;
+    }
+    // contact keys of sweep 0 handed in by the caller (stage_detect on every rank + gather)
+    const uint64_t* ext_keys = nullptr;
+    bool ext_given = false;
+    int64_t ext_n0 = 0, ext_candidates = 0, ext_coincident = 0;
+
     void sweep_positions(const Lane& ln, int sweep)
     {
         GridView g = grid_view();
@@ -598,7 +620,20 @@ public:
         uint32_t n0 = 0, cand = 0;
         int key_bits = 64;
         const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
-        {
+        if (sweep == 0 && ext_given) {
+            // the initial sweep's contact keys were detected elsewhere (slabs of slots on several
+            // ranks, gathered by the caller): take them as they are
+            n0 = (uint32_t)ext_n0; cand = (uint32_t)ext_candidates;
+            n_coincident = (uint32_t)ext_coincident;
+            g.slot_bits = slot_bits;
+            key_bits = pair_key_bits();
+            if (n0 > 0) {
+                ensure_contact_capacity(ln, n0);
+                be::copy_d2d(ln.s, h0[0].p, ext_keys, (size_t)n0 * 8);
+            }
+            ext_given = false;
+            predetected = false;
+        } else {
             const uint32_t* dctr = ctr;
             if (sweep == 0 && predetected) {
                 dctr = counters2.p;         // already computed on the side stream (this lane, or joined by the caller)
@@ -607,17 +642,15 @@ public:
                 detect_count(ln.s, scan_scratch, ctr, ln.small_groups);
             }
             ContactDetect d;
-            d.n = n; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
+            d.n = n; d.k0 = 0; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
             d.coincident_counter = nullptr;
             uint32_t three[4];
             readback_on(ln, three, dctr, 16);
             n0 = three[0]; cand = three[1];
             if (sweep == 0) n_coincident = three[3];
-            slot_bits = ceil_log2_u64((uint64_t)three[2] + 1);
-            if (slot_bits < 1) slot_bits = 1;
+            set_slot_bits(three[2]);
             g.slot_bits = slot_bits;
-            key_bits = ceil_log2_u64((uint64_t)cells) + 4 + 2 * slot_bits;
-            if (key_bits > 64) throw std::runtime_error("psim: grid cell population too large for the pair-key layout");
+            key_bits = pair_key_bits();
             if (n0 > 0) {
                 ensure_contact_capacity(ln, n0);
                 d.g = g;
@@ -988,7 +1021,11 @@ public:
     {
         be::stream_wait(st2, ev_drift);
         build_grid(st2, sort_tmp2);
-        if (cfg.stage_mask & kStageCollisions) { detect_count(st2, scan_tmp2, counters2.p, true); predetected = true; }
+        // (in a sharded step the caller may ask for the count pass of its own slab instead: stage_detect)
+        if ((cfg.stage_mask & kStageCollisions) && !sharded_step) {
+            detect_count(st2, scan_tmp2, counters2.p, true);
+            predetected = true;
+        }
         be::event_record(ev_side, st2);
         side_running = true;
     }
@@ -1092,6 +1129,43 @@ public:
     // has an exchange of accelerations to do starts that exchange first and calls this
     // while it is in flight.  Without the call, stage_kick_collide does the work itself.
     void stage_settle_positions() { settle_positions(); }
+    // Optional, after stage_gravity: contact detection of sweep 0 for the grid slots
+    // [k_lo, k_hi) only.  Every rank holds all positions, so a slab needs no halo exchange;
+    // the caller gathers the ranks' key lists and hands the whole list to
+    // stage_settle_positions_from().  out4 = {contacts found, candidate pairs examined, pairs
+    // at squared distance zero, keys written (0 if `cap` was too small: call again with
+    // room for out4[0] keys)}.  keys_out: device pointer.
+    void stage_detect(int64_t k_lo, int64_t k_hi, uint64_t* keys_out, int64_t cap, int64_t out4[4])
+    {
+        out4[0] = out4[1] = out4[2] = out4[3] = 0;
+        if (k_lo < 0 || k_hi > n || k_lo > k_hi || (k_hi > k_lo && (k_lo & 3)))
+            throw std::invalid_argument("psim: bad slot range");
+        if (!(cfg.stage_mask & kStageCollisions) || n == 0 || cfg.solver_iterations <= 0) return;
+        Lane ln = side_running ? side_lane() : main_lane();
+        detect_count(ln.s, *ln.scan_tmp, ln.ctr, ln.small_groups, k_lo, k_hi);
+        uint32_t four[4];
+        readback_on(ln, four, ln.ctr, 16);
+        set_slot_bits(four[2]);
+        out4[0] = four[0]; out4[1] = four[1]; out4[2] = four[3];
+        if (four[0] > 0 && (int64_t)four[0] <= cap && k_hi > k_lo) {
+            GridView g = grid_view();
+            ContactDetect d;
+            d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
+            d.first_pair = first_key.p; d.coincident_counter = nullptr; d.cand_counter = nullptr;
+            d.out_keys = keys_out; d.write_pass = 1;
+            be::launch(ln.s, k_hi - k_lo, d);
+            out4[3] = four[0];
+        }
+        be::sync(ln.s);      // the caller's exchange reads keys_out from another stream
+    }
+    void stage_settle_positions_from(const uint64_t* keys, int64_t n0, int64_t candidates, int64_t coincident)
+    {
+        if (n0 < 0 || n0 > 0x7fffffffLL || (n0 > 0 && !keys)) throw std::invalid_argument("psim: bad contact key list");
+        ext_keys = keys; ext_given = true;
+        ext_n0 = n0; ext_candidates = candidates; ext_coincident = coincident;
+        settle_positions();
+        ext_given = false;
+    }
     void stage_kick_collide(const vec2* acc_sorted)
     {
         be::launch(st, n, ScatterSorted{n, perm[sorted_key].p, acc_sorted, acc2.p});

@@ -27,6 +27,7 @@ EXPORTS = [
     "psim_stage_build", "psim_stage_gravity", "psim_stage_kick_collide", "psim_stage_conduction",
     "psim_stage_finish", "psim_brute_force_gravity", "psim_render_feed", "psim_pair_potential_energy",
     "psim_stage_conduction_exchanges", "psim_stage_settle_positions", "psim_time_walk",
+    "psim_stage_detect", "psim_stage_settle_positions_from",
 ]
 
 
@@ -97,6 +98,8 @@ def load(path=None):
     L.psim_stage_gravity.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.psim_stage_kick_collide.argtypes = [vp, vp]
     L.psim_stage_settle_positions.argtypes = [vp]
+    L.psim_stage_detect.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+    L.psim_stage_settle_positions_from.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
     L.psim_time_walk.argtypes = [vp, ctypes.c_int32, ctypes.c_double, c_dp]
     L.psim_stage_conduction.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp]
     L.psim_stage_finish.argtypes = [vp, vp]

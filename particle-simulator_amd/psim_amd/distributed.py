@@ -9,6 +9,11 @@ dominate the step are split by range and their outputs exchanged:
   * gravity: rank r walks the tree for a contiguous range of Morton-sorted
     target particles; accelerations are all-gathered in sorted order (16 B per
     particle) -- one all-gather per step;
+  * contact detection: rank r sweeps a contiguous range of grid slots (cells are
+    row-major, so that is a slab of the domain; every rank holds all positions,
+    so a slab needs no halo) and the ranks' contact key lists are all-gathered
+    (8 B per contact, a few per cent of the particle count); the contact solver
+    itself runs on every rank on the gathered list;
   * conduction + cooling: when the step needs the full neighbour sweep, rank r
     sweeps a contiguous range of grid slots (whole runs of row-major cells, i.e. a
     spatial slab) and temperatures are all-gathered in slot order (8 B per
@@ -55,6 +60,49 @@ class ShardedParticleSystem(ParticleSystem):
         _, _, per = shard_range(n, 0, self._world)
         self._acc = torch.zeros((per * self._world, 2), dtype=torch.float64, device=self._tdev)
         self._tmp = torch.zeros((per * self._world,), dtype=torch.float64, device=self._tdev)
+        self._keys = torch.zeros((max(4096, per // 8),), dtype=torch.int64, device=self._tdev)
+        self._all_keys = None
+        # the small exchanges of the contact lists run on a stream of their own, so that they
+        # are not ordered behind the walk (which is on the default stream)
+        self._side = torch.cuda.Stream(device=self._tdev) if self._tdev.type == "cuda" else None
+
+    def _detect_and_gather(self, lo, hi):
+        """contact detection of the first collision sweep on this rank's slab of grid slots,
+        then the ranks' key lists gathered -> (tensor of all keys, contacts, candidates,
+        coincident pairs)"""
+        L, ctx = self._lib, self._ctx
+        out = (ctypes.c_int64 * 4)()
+        while True:
+            _capi.check(L, L.psim_stage_detect(ctx, lo, hi, ctypes.c_void_p(self._keys.data_ptr()),
+                                               self._keys.numel(), out))
+            if out[3] == out[0]:
+                break
+            self._keys = torch.zeros((int(out[0]) + int(out[0]) // 4 + 4096,), dtype=torch.int64, device=self._tdev)
+        mine = [int(out[0]), int(out[1]), int(out[2])]
+        if self._world == 1:
+            return self._keys, mine[0], mine[1], mine[2]
+        import contextlib
+        side = torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
+        with side:
+            counts = torch.tensor(mine, dtype=torch.int64, device=self._tdev)
+            every = torch.zeros((self._world * 3,), dtype=torch.int64, device=self._tdev)
+            dist.all_gather_into_tensor(every, counts, group=self._group)
+            every = every.cpu().view(self._world, 3)
+            n_each = [int(v) for v in every[:, 0]]
+            most = max(n_each)
+            total = sum(n_each)
+            if most == 0:
+                return self._keys, 0, int(every[:, 1].sum()), int(every[:, 2].sum())
+            if self._keys.numel() < most:        # the padded send buffer must hold the longest list
+                grown = torch.zeros((most + most // 4 + 4096,), dtype=torch.int64, device=self._tdev)
+                grown[: mine[0]] = self._keys[: mine[0]]
+                self._keys = grown
+            padded = torch.empty((self._world * most,), dtype=torch.int64, device=self._tdev)
+            dist.all_gather_into_tensor(padded, self._keys[:most], group=self._group)
+            self._all_keys = torch.cat([padded[r * most: r * most + n_each[r]] for r in range(self._world)])
+            if self._side is not None:
+                self._side.synchronize()
+        return self._all_keys, total, int(every[:, 1].sum()), int(every[:, 2].sum())
 
     def _gather(self, buf, per, async_op=False):
         """in-place all-gather of the ranks' equal shards of buf[: per * world];
@@ -77,8 +125,16 @@ class ShardedParticleSystem(ParticleSystem):
             # flight the half of the contact solver that needs no velocities runs on the
             # library's second stream.
             _capi.check(L, L.psim_stage_gravity(ctx, lo, hi, ctypes.c_void_p(self._acc.data_ptr())))
+            detected = None
+            if (self._stage_mask & _capi.STAGE_COLLISIONS) and n > 0:
+                detected = self._detect_and_gather(lo, hi)
             work = self._gather(self._acc, per, async_op=True)
-            _capi.check(L, L.psim_stage_settle_positions(ctx))
+            if detected is not None:
+                keys, n_keys, cand, coinc = detected
+                _capi.check(L, L.psim_stage_settle_positions_from(ctx, ctypes.c_void_p(keys.data_ptr()), n_keys,
+                                                                  cand, coinc))
+            else:
+                _capi.check(L, L.psim_stage_settle_positions(ctx))
             if work is not None:
                 work.wait()
             if self._tdev.type == "cuda":
