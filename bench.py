@@ -124,8 +124,8 @@ def main():
     from psim_amd.particle_system import ParticleSystem
     # N = 1: C2 (4Mi, the single-GPU configuration the metric is quoted on).
     # N > 1: C3 (16Mi rotating disk), ONE simulation sharded over the N ranks: every
-    # rank holds the state, gravity is split by sorted-target range and conduction by
-    # grid-slot range, outputs all-gathered over RCCL (psim_amd/distributed.py).
+    # rank holds the state, gravity is split by sorted-target range, contact detection and
+    # conduction by grid-slot range, outputs all-gathered over RCCL (psim_amd/distributed.py).
     wl = args.workload or ("c2" if world == 1 else "c3")
     label, n, bounds, state, mask = workload(wl)
     if world > 1:
@@ -185,8 +185,8 @@ def main():
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": label, "particles": n, "theta": SIM["barnes_hut_theta"],
-                       "multi_gpu": ("one simulation sharded over %d ranks: walk by sorted-target range, "
-                                     "conduction by grid-slot range, RCCL all-gather" % world) if world > 1 else "single"},
+                       "multi_gpu": ("one simulation sharded over %d ranks: walk by sorted-target range, contact detection "
+                                     "and conduction by grid-slot slabs, RCCL all-gathers" % world) if world > 1 else "single"},
             "roofline": {"kernel": "gravity_walk_multi_kernel", "bound": "valu", "achieved": achieved,
                          "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": None,
