@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--walk-mode", type=int, default=0)
     ap.add_argument("--library", default=None, help="alternative build of libpsim_hip.so (kernel experiments)")
+    ap.add_argument("--staged", action="store_true",
+                    help="drive the step through the psim_stage_* entry points (the multi-GPU path) even on one GPU")
     ap.add_argument("--no-overlap", action="store_true",
                     help="every stage on one stream (kernel timings without the side stream's contention)")
     ap.add_argument("--brute", type=int, default=0,
@@ -118,8 +120,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or args.staged:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from psim_amd.particle_system import ParticleSystem
     # N = 1: C2 (4Mi, the single-GPU configuration the metric is quoted on).
@@ -128,7 +137,7 @@ def main():
     # conduction by grid-slot range, outputs all-gathered over RCCL (psim_amd/distributed.py).
     wl = args.workload or ("c2" if world == 1 else "c3")
     label, n, bounds, state, mask = workload(wl)
-    if world > 1:
+    if world > 1 or args.staged:
         from psim_amd.distributed import ShardedParticleSystem
         ps = ShardedParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds, device=local_rank,
                                    stage_mask=mask, walk_mode=args.walk_mode, state=state)
@@ -219,7 +228,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.staged:
         dist.barrier()
         dist.destroy_process_group()
 

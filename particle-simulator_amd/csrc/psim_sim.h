@@ -179,7 +179,9 @@ public:
         if (e) per_simd = atof(e);
         else if (cfg.overlap != 0 && n > 0) {
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
-            else per_simd = (n < (8ll << 20)) ? 6 : 7;
+            // (a sharded step also leaves room for the exchange's own kernels, whose workgroups
+            // of up to 512 lanes need two free slots on every SIMD of a CU)
+            else per_simd = (n < (8ll << 20) || sharded_step) ? 6 : 7;
         }
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
