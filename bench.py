@@ -112,6 +112,12 @@ def main():
                     help="also time the all-pairs cross-check kernel on this many particles")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: libraries that print there (RCCL announces its
+    # version on stdout when a communicator is created) are sent to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -227,7 +233,8 @@ def main():
             bs.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.staged:
         dist.barrier()
         dist.destroy_process_group()
