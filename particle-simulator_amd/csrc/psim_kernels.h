@@ -36,6 +36,18 @@ __device__ __forceinline__ void aggregated_inc(uint32_t* p)
 }
 #endif
 
+// *p = max(*p, v).  The current value is looked at first and the atomic only issued by lanes
+// that would raise it: a maximum over many lanes then costs a handful of atomics, not one
+// same-address atomic per wave (a stale look only costs a needless atomic).
+#if defined(PSIM_HOSTLOOP)
+inline void raise_to_u32(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
+#else
+__device__ __forceinline__ void raise_to_u32(uint32_t* p, uint32_t v)
+{
+    if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
+}
+#endif
+
 // quadtree.py:13-19 (_get_quadrant) + :24-38,62-63 (child boxes, centre = x + w/2):
 // descend 32 levels from the root box exactly as an insertion would, recording
 // quadrant = 2*(y >= cy) + (x >= cx) per level, most significant first.
@@ -755,6 +767,43 @@ PSIM_HD PSIM_FORCEINLINE void for_each_slot_in_cell(const GridView& g, uint32_t 
     for (int32_t b = g.offsets[nc]; b < g.offsets[nc + 1]; ++b) f((uint32_t)b);
 }
 
+// The slots for_each_slot_in_cell would visit, as a range [lo, hi) (the caller skips k itself
+// when which == 0).  False: nothing to visit.
+PSIM_HD PSIM_FORCEINLINE bool cell_slot_range(const GridView& g, const CellBody& me, int which, int32_t* lo, int32_t* hi)
+{
+    uint32_t c = me.cell;
+    if (which != 0) {
+        int idx = which - 1;
+        if (idx == 4) return false;
+        int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
+        int nx = cx + (idx % 3 - 1), ny = cy + (idx / 3 - 1);
+        if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) return false;
+        c = (uint32_t)(ny * g.gw + nx);
+    }
+    *lo = g.offsets[c];
+    *hi = g.offsets[c + 1];
+    return *hi > *lo;
+}
+
+// F(record of slot y, aux[y] (0 without aux), y) for y in [lo, hi) except `skip`, in ascending order, with
+// the records and aux words of four slots fetched before the first of them is looked at.
+template <class F>
+PSIM_HD PSIM_FORCEINLINE void sweep_slots4(const CellBody* PSIM_RESTRICT body, const int32_t* PSIM_RESTRICT aux,
+                                           int32_t lo, int32_t hi, uint32_t skip, F f)
+{
+    for (int32_t b = lo; b < hi; b += 4) {
+        const int32_t last = hi - 1;
+        const int32_t b1 = b + 1 < hi ? b + 1 : last, b2 = b + 2 < hi ? b + 2 : last, b3 = b + 3 < hi ? b + 3 : last;
+        const CellBody o0 = body[b], o1 = body[b1], o2 = body[b2], o3 = body[b3];
+        int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (aux) { a0 = aux[b]; a1 = aux[b1]; a2 = aux[b2]; a3 = aux[b3]; }
+        if ((uint32_t)b != skip) f(o0, a0, (uint32_t)b);
+        if (b + 1 < hi && (uint32_t)(b + 1) != skip) f(o1, a1, (uint32_t)(b + 1));
+        if (b + 2 < hi && (uint32_t)(b + 2) != skip) f(o2, a2, (uint32_t)(b + 2));
+        if (b + 3 < hi && (uint32_t)(b + 3) != skip) f(o3, a3, (uint32_t)(b + 3));
+    }
+}
+
 // Sweep 0: test every candidate pair against the sweep's initial positions and
 // collect the keys of those in contact (unordered between lanes; sorted
 // afterwards).  Two passes around an exclusive scan instead of an atomic
@@ -964,7 +1013,6 @@ struct ContactSimulate {
     uint32_t round;
     vec2* out;                // [2h + side] position after contact h
     double* geo;              // [3h] normal and PE change
-    uint32_t* executed;
     const CellBody* body;     // initial positions
     const double* mass;
     double G, soft, pos_correct;
@@ -989,7 +1037,6 @@ struct ContactSimulate {
         out[2 * h + 1] = J;
         geo[3 * h] = v[0]; geo[3 * h + 1] = v[1]; geo[3 * h + 2] = v[2];
         done[h] = round;
-        aggregated_inc(executed);
     }
 };
 
@@ -1037,11 +1084,18 @@ struct ContactVelocity {
     }
 };
 
+// contacts still waiting on a predecessor, and the highest round any contact ran in
 struct CountPending {
     int64_t n;
     const uint32_t* done;
     uint32_t* pending;
-    PSIM_HD void operator()(int64_t h) const { if (done[h] == 0) aggregated_inc(pending); }
+    uint32_t* last_round;
+    PSIM_HD void operator()(int64_t h) const
+    {
+        uint32_t d = done[h];
+        if (d == 0) aggregated_inc(pending);
+        else raise_to_u32(last_round, d);
+    }
 };
 
 // position of a slot as seen by the candidate pair with ordering key t: the
@@ -1075,10 +1129,10 @@ struct SegDisplacement {
     const vec2* out;
     const CellBody* body;
     double* dseg;
-    uint32_t* zero_word;       // cleared here for the counting pass that follows
+    uint32_t* zero_word;       // [0] and [5] are cleared here for the counting pass that follows
     PSIM_HD void operator()(int64_t e) const
     {
-        if (e == 0) *zero_word = 0u;
+        if (e == 0) { zero_word[0] = 0u; zero_word[5] = 0u; }
         uint32_t x = (uint32_t)(adj[e] >> 32);
         if (cseg[x] != (int32_t)e) return;
         double x0 = body[x].x, y0 = body[x].y, m = 0.0;
@@ -1430,8 +1484,9 @@ struct ConductionPairs {
         const CellBody bx = g.body[x];
         uint32_t found = 0;
         uint32_t at = write_pass ? offsets[t] : 0u;
-        for_each_slot_in_cell(g, x, which, [&](uint32_t y) {
-            const CellBody by = g.body[y];
+        int32_t lo = 0, hi = 0;
+        if (cell_slot_range(g, bx, which, &lo, &hi))
+        sweep_slots4(g.body, (const int32_t*)nullptr, lo, hi, x, [&](const CellBody& by, int32_t, uint32_t y) {
             double dx = by.x - bx.x, dy = by.y - bx.y;
             double d2 = dx * dx + dy * dy;
             double cd = (double)(bx.r + by.r);

@@ -200,6 +200,7 @@ public:
     Lane main_lane() { return Lane{st, &sort_tmp, &scan_tmp, counters.p, &mailbox, false}; }
     Lane side_lane() { return Lane{st2, &sort_tmp2, &scan_tmp2, counters2.p, &mailbox2, true}; }
     // what the position half leaves for the velocity half of the same sweep
+    int rounds_hint = 6;               // dependency rounds launched before the first re-test of an iteration
     uint32_t settled_contacts = 0, settled_rounds = 0;
     uint64_t* settled_adj = nullptr;
     bool positions_settled = false;    // sweep 0's position half has run for this step
@@ -669,7 +670,7 @@ public:
         int hn_which = 0;
         uint32_t nH = n0;
         uint64_t* adjs = nullptr;
-        uint32_t round = 0;
+        uint32_t round = 0, last_exec = 0;
         for (int iter = 0;; ++iter) {
             ++solver_fixpoint_iters;
             if (iter > 100000) throw std::runtime_error("psim: collision solver did not converge");
@@ -690,13 +691,15 @@ public:
                     ++round;
                     ContactSimulate sm;
                     sm.n = nH; sm.hsi = hsi.p; sm.hsj = hsj.p; sm.prev = prevl.p; sm.done = done.p; sm.round = round;
-                    sm.out = outp.p; sm.geo = cgeo.p; sm.executed = ctr + 3; sm.body = cbody.p;
+                    sm.out = outp.p; sm.geo = cgeo.p; sm.body = cbody.p;
                     sm.mass = mass.p; sm.G = cfg.gravity_constant; sm.soft = cfg.softening; sm.pos_correct = cfg.pos_correct;
                     be::launch(ln.s, nH, sm);
                 }
                 solver_rounds += count;
             };
-            run_rounds(6);
+            // as many rounds up front as the last execution needed, plus one (a round with nothing
+            // to do costs a few microseconds, a re-test that saw unfinished contacts is thrown away)
+            run_rounds(rounds_hint);
             // ---- re-test what the hypothesis could have changed (count, scan, write)
             uint32_t nNew = 0;
             {
@@ -712,18 +715,23 @@ public:
                 r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
                 rp.carry = ContactCarryClean{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
-                rp.pending = CountPending{(int64_t)nH, done.p, ctr + 1};
+                rp.pending = CountPending{(int64_t)nH, done.p, ctr + 1, ctr + 6};
                 rp.nt = nt; rp.n0 = n0;
                 for (;;) {
                     be::launch(ln.s, ntot + nH, rp);
                     be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, (uint64_t)ntot, scan_scratch.p, ctr, ln.small_groups);
-                    uint32_t two[2];
-                    readback_on(ln, two, ctr, 8);
+                    uint32_t two[7];
+                    readback_on(ln, two, ctr, 28);
                     nNew = two[0];
-                    if (two[1] == 0) break;
+                    if (two[1] == 0) {
+                        last_exec = two[6];
+                        int want = (int)two[6] + 1;
+                        rounds_hint = want < 2 ? 2 : (want > 4096 ? 4096 : want);
+                        break;
+                    }
                     // contacts were still waiting on predecessors: the re-test above saw incomplete
                     // versions; run further rounds and re-test again
-                    if (round > 6 + nH) throw std::runtime_error("psim: internal: contact schedule stalled");
+                    if (round > 4102 + nH) throw std::runtime_error("psim: internal: contact schedule stalled");
                     run_rounds(6);
                     be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 1});
                 }
@@ -769,7 +777,7 @@ public:
         be::launch(ln.s, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
         // (ContactFinalizePositions has already marked every touched slot clean again)
         n_moved += read_u32(ln, ctr + 5);
-        settled_contacts = nH; settled_rounds = round; settled_adj = adjs;
+        settled_contacts = nH; settled_rounds = last_exec; settled_adj = adjs;
     }
 
     // velocity half of the sweep whose position half ran last (main stream)

@@ -15,10 +15,25 @@ from psim_amd.particle_system import ParticleSystem
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 26
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-side = float(np.sqrt(n / 1e-3))            # 1e-3 particles per square pixel, as config.json
-bounds = (side * np.sqrt(2.0), side / np.sqrt(2.0))
+dense_hot = len(sys.argv) > 3 and sys.argv[3] == "c4"
 t0 = time.time()
-ps = ParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds)
+if dense_hot:
+    # the dense cold-collapse stress case: a uniform disk at 4x the default density (64 Mi
+    # particles: R = 73078 in 150000 x 150000), at rest, temperatures U[0.5, 0.9] so that
+    # collision heating pushes particles past the explosion threshold
+    from bench import disk_state
+    radius = float(np.sqrt(n / (np.pi * 4e-3)))
+    side = 2.0 * radius * 1.0263
+    bounds = (side, side)
+    sim = dict(SIM, min_temp=0.5, max_temp=0.9)
+    rng = np.random.default_rng(42)
+    state = disk_state(n, bounds, radius, rng)
+    state["temperatures"] = rng.uniform(0.5, 0.9, (n, 1))
+    ps = ParticleSystem(n, sim, np.random.default_rng(42), bounds, state=state)
+else:
+    side = float(np.sqrt(n / 1e-3))            # 1e-3 particles per square pixel, as config.json
+    bounds = (side * np.sqrt(2.0), side / np.sqrt(2.0))
+    ps = ParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds)
 print("init %.1f s" % (time.time() - t0), flush=True)
 m0 = float(ps.masses.sum())
 ps._calculate_gravity()
@@ -30,10 +45,12 @@ for k in range(steps):
     print("step %d: %.1f ms  %s" % (k, (time.time() - t) * 1e3, c), flush=True)
     print("   stages", {a: round(b, 2) for a, b in ps.stage_times_ms().items()}, flush=True)
     assert c["tree_nodes"] == 1 + 4 * c["internal_nodes"]
+    n_now = c["particles"]
 e1 = ps.get_energies()
 print("energies before", e0, "after", e1)
 assert np.isfinite(e1).all()
 assert abs(float(ps.masses.sum()) - m0) <= 1e-9 * m0 or c["particles"] < n
+assert ps.num_particles == n_now and ps.positions.shape == (n_now, 2)
 acc = ps.accelerations
 assert np.isfinite(acc).all() and np.isfinite(ps.positions).all()
 print("ok")
