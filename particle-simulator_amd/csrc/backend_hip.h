@@ -950,11 +950,17 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
     const int lane = threadIdx.x;
     const uint32_t total_elems_arg = total_elems;
     uint32_t chunk = blockIdx.x;
+    bool first = true;
   for (;;) {
     if (chunk_counter) {
-        uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&chunk_counter[0], 1u);
-        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        // a wave's first chunk is its own number (no burst of same-address atomics when the
+        // kernel starts); the counter hands out the chunks after those
+        if (!first) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&chunk_counter[0], 1u);
+            chunk = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        }
+        first = false;
         if (chunk >= nchunks) {
             if (lane == 0 && atomicAdd(&chunk_counter[1], 1u) == gridDim.x - 1) {
                 __hip_atomic_store(&chunk_counter[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
