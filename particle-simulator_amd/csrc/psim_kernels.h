@@ -929,8 +929,10 @@ struct AdjLinks {
     const uint32_t* hsi;
     int32_t* cseg;       // slot -> first adjacency entry (-1 = clean)
     int32_t* prev;       // [2h + side]
+    uint32_t* zero_word; // cleared here: SegDisplacement raises it to the largest displacement bound
     PSIM_HD void operator()(int64_t e) const
     {
+        if (e == 0) *zero_word = 0u;
         uint32_t slot = (uint32_t)(adj[e] >> 32), h = (uint32_t)adj[e];
         bool first = (e == 0) || ((uint32_t)(adj[e - 1] >> 32) != slot);
         if (first) cseg[slot] = (int32_t)e;
@@ -1117,6 +1119,44 @@ PSIM_HD PSIM_FORCEINLINE vec2 versioned_pos(uint32_t slot, uint64_t t, const int
     return out[2 * last + side];
 }
 
+// positive float <-> its bit pattern (positive floats order like their bit patterns, and a
+// NaN pattern is above them all)
+PSIM_HD PSIM_FORCEINLINE uint32_t float_bits_at_least(double v)
+{
+    float f = (float)v;
+    if ((double)f < v) f = f * 1.0000002f;      // next float or the one after
+    uint32_t b;
+    __builtin_memcpy(&b, &f, 4);
+    return b;
+}
+PSIM_HD PSIM_FORCEINLINE double double_of_float_bits(uint32_t b)
+{
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return (double)f;
+}
+
+// Is every position that the grid assigns to neighbour cell `which` (1..9, not 5) of slot
+// `me` further than `reach` from me's position?  A cell holds the positions whose
+// coordinate / cell_size truncates to its column and row (particle_system.py:744-749); the
+// cells of the first and last column / row also hold everything clipped into them, so they
+// are unbounded outwards.  Conservative by a millionth of a pixel against rounding.
+PSIM_HD PSIM_FORCEINLINE bool cell_beyond_reach(const GridView& g, double cell_size, const CellBody& me, int which,
+                                                double reach)
+{
+    int idx = which - 1;
+    int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
+    int nx = cx + (idx % 3 - 1), ny = cy + (idx / 3 - 1);
+    if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) return true;       // no such cell
+    double gx = 0.0, gy = 0.0;
+    if (nx > 0) { double lo = (double)nx * cell_size - me.x; if (lo > gx) gx = lo; }
+    if (nx < g.gw - 1) { double hi = me.x - (double)(nx + 1) * cell_size; if (hi > gx) gx = hi; }
+    if (ny > 0) { double lo = (double)ny * cell_size - me.y; if (lo > gy) gy = lo; }
+    if (ny < g.gh - 1) { double hi = me.y - (double)(ny + 1) * cell_size; if (hi > gy) gy = hi; }
+    double r = reach + 1e-6;
+    return gx * gx + gy * gy > r * r;     // false for NaN: nothing is skipped
+}
+
 // For each touched slot: how far any of its versioned positions lies from its
 // initial one (inflated so that rounding can never make the bound too small).
 // Stored at the slot's first adjacency entry.  Lets the re-test discard, exactly,
@@ -1129,6 +1169,7 @@ struct SegDisplacement {
     const vec2* out;
     const CellBody* body;
     double* dseg;
+    uint32_t* dmax_bits;       // raised to the largest bound of all slots (float bit pattern)
     uint32_t* zero_word;       // [0] and [5] are cleared here for the counting pass that follows
     PSIM_HD void operator()(int64_t e) const
     {
@@ -1144,7 +1185,9 @@ struct SegDisplacement {
             double d2 = dx * dx + dy * dy;
             m = d2 > m ? d2 : m;
         }
-        dseg[e] = sqrt(m) * (1.0 + 1e-6) + 1e-9;
+        double bound = sqrt(m) * (1.0 + 1e-6) + 1e-9;
+        dseg[e] = bound;
+        raise_to_u32(dmax_bits, float_bits_at_least(bound));
     }
 };
 
@@ -1164,6 +1207,12 @@ struct ContactRetest {
     const uint32_t* hsi;
     const vec2* out;
     const double* dseg;
+    // prune: the sweep's initial positions are the ones the grid was built from, so a whole
+    // neighbour cell can be skipped when its region lies beyond contact distance plus the
+    // displacement bounds (largest radius r_max, largest bound of any slot *dmax_bits)
+    int32_t prune, r_max;
+    double cell_size;
+    const uint32_t* dmax_bits;
     uint32_t* counts;
     const uint32_t* offsets;
     uint64_t* first_key;       // count pass: key of an element's first hit
@@ -1186,6 +1235,9 @@ struct ContactRetest {
             int32_t rx = bx.r;
             double reach_x = dseg[e];
             uint32_t at = write_pass ? offsets[t] : 0u;
+            const bool skip_cell = prune && which != 0 && which != 5 &&
+                cell_beyond_reach(g, cell_size, bx, which, (double)(rx + r_max) + reach_x + double_of_float_bits(*dmax_bits));
+            if (!skip_cell)
             for_each_slot_in_cell(g, x, which, [&](uint32_t y) {
                 const CellBody by = g.body[y];
                 uint32_t py = by.idx;

@@ -77,6 +77,7 @@ public:
     uint32_t n_internal = 0;
     int sorted_key = 0, sorted_ckey = 0;
     int slot_bits = 1;            // pair-key field width, from the largest cell population
+    int32_t max_radius = 0;       // largest radius uploaded (an upper bound after explosions removed particles)
 
     // state (index space; reference layout particle_system.py:370-376, radii narrowed)
     DevBuf<vec2> pos, vel, acc, acc2;
@@ -281,6 +282,12 @@ public:
         if (count < 0 || count > 0x7fff0000LL) throw std::invalid_argument("psim: particle count out of range");
         n = count;
         size_t c = (size_t)count;
+        max_radius = 0;
+        for (size_t i = 0; i < c; ++i) {
+            int64_t r = h_radii[i];
+            if (r < 0 || r > (1 << 24)) throw std::invalid_argument("psim: radius out of range");
+            if (r > max_radius) max_radius = (int32_t)r;
+        }
         pos.ensure(c); vel.ensure(c); acc.ensure(c); acc2.ensure(c);
         mass.ensure(c); inv_mass.ensure(c); temp.ensure(c); radii.ensure(c);
         be::copy_h2d(st, pos.p, h_pos, c * 16);
@@ -681,7 +688,7 @@ public:
             // field alone leaves each slot's contacts in order
             int sa = be::radix_sort_pairs<uint64_t>(ln.s, ka, nullptr, 2ull * nH, 32, 32 + slot_field_bits, ln.sort_tmp->p);
             adjs = adj[sa].p;
-            be::launch(ln.s, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p});
+            be::launch(ln.s, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p, ctr + 7});
             // Dependency rounds.  A first batch is launched without asking how far it got (a
             // round with nothing ready is a no-op); whether contacts are still pending is read
             // back together with the re-test count below, and only then are more rounds run.
@@ -707,11 +714,12 @@ public:
                 pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)ntot);
                 scan_scratch.ensure_zero(ln.s, be::scan_temp_words((uint64_t)ntot));
                 dseg.ensure(2 * (size_t)nH);
-                be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 1});
+                be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1});
                 RetestPass rp;
                 ContactRetest& r = rp.retest;
                 r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outp.p;
                 r.dseg = dseg.p;
+                r.prune = sweep == 0 ? 1 : 0; r.r_max = max_radius; r.cell_size = (double)cfg.cell_size; r.dmax_bits = ctr + 7;
                 r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
                 rp.carry = ContactCarryClean{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
@@ -733,7 +741,7 @@ public:
                     // versions; run further rounds and re-test again
                     if (round > 4102 + nH) throw std::runtime_error("psim: internal: contact schedule stalled");
                     run_rounds(6);
-                    be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 1});
+                    be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1});
                 }
                 if (nNew > ccap) {
                     // growing reallocates every contact buffer: restart the whole sweep
