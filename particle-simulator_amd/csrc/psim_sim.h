@@ -158,20 +158,20 @@ public:
     // stream in use the walk therefore runs as a fixed set of waves that take chunks of targets
     // from a counter and leave the remaining slots of every SIMD to the other stream for the
     // whole walk.  What runs there is latency-bound and slows down by about the share of slots
-    // it is denied, while the walk slows down less than its share (4 Mi: 4.15 / 4.32 / 4.71 /
-    // 5.15 ms at 8 / 7 / 6 / 5 slots), so:
-    //   below 8 Mi particles the grid build and the whole position half of the collision stage
-    //   run underneath 6 of 8 slots (4 Mi: step 6.5 -> 6.2 ms);
-    //   from 8 Mi on only the grid build and the first count pass do, underneath 7 of 8 -- the
-    //   position half would not finish under the walk at any setting that pays (16 Mi: 7 slots
-    //   18.7 ms, 6 slots 18.9 ms, against 17.6 ms with the position half after the walk).
+    // it is denied, while the walk slows down less than its share (4 Mi, walk alone: 3.90 / 4.08 /
+    // 4.38 / 4.86 ms at 8 / 7 / 6 / 5 slots).  With collisions on, the grid build and the whole
+    // position half of the collision stage run underneath 6 of 8 slots (4 Mi: step 6.5 -> 5.9 ms;
+    // 16 Mi: 18.1 ms with 7 slots and the position half after the walk, 17.4 with 6, 17.2 with
+    // 5.5, 17.7 with 5).  Without collisions only the grid build is there: 7 slots from 8 Mi
+    // particles on, the whole grid below.  Two free slots per SIMD are also what the exchange
+    // kernels of a sharded step need (workgroups of up to 512 lanes).
     // PSIM_WALK_WAVES=<per SIMD> and PSIM_POSITIONS_UNDER_WALK=<0|1> override (kernel experiments).
     bool sharded_step = false;     // the step in progress is driven through the stage_* calls
     bool positions_under_walk() const
     {
         static const char* e = getenv("PSIM_POSITIONS_UNDER_WALK");
         if (e) return atoi(e) != 0;
-        return cfg.overlap != 0 && (n < (8ll << 20) || sharded_step);
+        return cfg.overlap != 0;
     }
     int64_t walk_resident_waves() const
     {
@@ -180,9 +180,7 @@ public:
         if (e) per_simd = atof(e);
         else if (cfg.overlap != 0 && n > 0) {
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
-            // (a sharded step also leaves room for the exchange's own kernels, whose workgroups
-            // of up to 512 lanes need two free slots on every SIMD of a CU)
-            else per_simd = (n < (8ll << 20) || sharded_step) ? 6 : 7;
+            else per_simd = 6;
         }
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
