@@ -1192,9 +1192,10 @@ struct SegDisplacement {
 };
 
 // Re-test, against the versioned positions, every candidate pair that involves
-// a slot touched by a hypothesised contact.  Element index = adjacency entry *
-// 10 + cell selector (the nine cells of one touched slot are re-tested by
-// different lanes); only the first entry of a slot's segment works.  A pair of
+// a slot touched by a hypothesised contact.  Element index = cell selector *
+// n_adj + adjacency entry (the nine cells of one touched slot are re-tested by
+// different lanes; 20 n_H elements, fewer than 2^32); only the first entry of a
+// slot's segment works.  A pair of
 // two touched slots is emitted once, by the slot whose particle index is lower.
 // Two passes around a scan, like ContactDetect: counts[t] and the first hit's key,
 // then keys at offsets[t] (elements with two or more hits redo their tests).
@@ -1225,8 +1226,12 @@ struct ContactRetest {
             if (c == 0) return;
             if (c == 1) { out_keys[offsets[t]] = first_key[t]; return; }
         }
-        int64_t e = t / 10;
-        int which = (int)(t - e * 10);
+        // element = cell selector * n_adj + adjacency entry: the lanes of a wave look at the same
+        // one of the nine cells for 64 consecutive entries, so they run loops of similar length
+        // (and a wave whose cell is out of reach for all of them ends at once)
+        const uint32_t which_u = (uint32_t)t / (uint32_t)n_adj;
+        int64_t e = t - (int64_t)which_u * n_adj;
+        int which = (int)which_u;
         uint32_t x = (uint32_t)(adj[e] >> 32);
         uint32_t found = 0;
         if (cseg[x] == (int32_t)e) {
@@ -1515,7 +1520,7 @@ struct WriteMoved {
     }
 };
 
-// element = touched slot index * 10 + cell selector.  Emits, for every touching pair
+// element = cell selector * n_moved + touched slot's list entry.  Emits, for every touching pair
 // found, two entries (target slot << 32 | source slot).  A pair of two touched slots
 // is emitted by the one with the lower particle index.  count / scan / write.
 struct ConductionPairs {
@@ -1530,8 +1535,9 @@ struct ConductionPairs {
     PSIM_HD void operator()(int64_t t) const
     {
         if (write_pass && counts[t] == 0) return;
-        int64_t m = t / 10;
-        int which = (int)(t - m * 10);
+        const uint32_t which_u = (uint32_t)t / (uint32_t)n_moved;     // element = cell selector * n_moved + list entry
+        int64_t m = t - (int64_t)which_u * n_moved;
+        int which = (int)which_u;
         uint32_t x = list[m];
         const CellBody bx = g.body[x];
         uint32_t found = 0;

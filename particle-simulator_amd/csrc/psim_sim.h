@@ -709,6 +709,7 @@ public:
             uint32_t nNew = 0;
             {
                 int64_t nt = 20ll * nH, ntot = nt + n0;
+                if (nt >= (1ll << 32)) throw std::runtime_error("psim: too many contacts for one sweep");
                 pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)ntot);
                 scan_scratch.ensure_zero(ln.s, be::scan_temp_words((uint64_t)ntot));
                 dseg.ensure(2 * (size_t)nH);
