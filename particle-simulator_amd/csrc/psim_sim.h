@@ -160,9 +160,11 @@ public:
     // whole walk.  What runs there is latency-bound and slows down by about the share of slots
     // it is denied, while the walk slows down less than its share (4 Mi, walk alone: 3.90 / 4.08 /
     // 4.38 / 4.86 ms at 8 / 7 / 6 / 5 slots).  With collisions on, the grid build and the whole
-    // position half of the collision stage run underneath 6 of 8 slots (4 Mi: step 6.5 -> 5.9 ms;
-    // 16 Mi: 18.1 ms with 7 slots and the position half after the walk, 17.4 with 6, 17.2 with
-    // 5.5, 17.7 with 5).  Without collisions only the grid build is there: 7 slots from 8 Mi
+    // position half of the collision stage run underneath 6.5 of 8 slots below 8 Mi particles
+    // (26 walk waves per CU; 4 Mi: step 5.91 / 5.79 / 5.77 / 6.23 ms at 6 / 6.5 / 6.75 / 7 -- past
+    // the optimum the side work no longer ends with the walk) and underneath 6 from there on
+    // (16 Mi: 16.9 ms at 5.5 and at 6, 17.7 at 6.5, 18.1 with 7 and the position half after
+    // the walk).  Without collisions only the grid build is there: 7 slots from 8 Mi
     // particles on, the whole grid below.  Two free slots per SIMD are also what the exchange
     // kernels of a sharded step need (workgroups of up to 512 lanes).
     // PSIM_WALK_WAVES=<per SIMD> and PSIM_POSITIONS_UNDER_WALK=<0|1> override (kernel experiments).
@@ -180,7 +182,7 @@ public:
         if (e) per_simd = atof(e);
         else if (cfg.overlap != 0 && n > 0) {
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
-            else per_simd = 6;
+            else per_simd = (n < (8ll << 20) && !sharded_step) ? 6.5 : 6;
         }
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
