@@ -1242,6 +1242,27 @@ struct ContactRetest {
             uint32_t at = write_pass ? offsets[t] : 0u;
             const bool skip_cell = prune && which != 0 && which != 5 &&
                 cell_beyond_reach(g, cell_size, bx, which, (double)(rx + r_max) + reach_x + double_of_float_bits(*dmax_bits));
+            // Two phases, so that the lanes of a wave do the expensive part together: first the
+            // cell's slots are filtered by reach (cheap, every lane in step), the few that pass
+            // are remembered; then each lane settles its candidates (ordering key, versioned
+            // positions, contact test).  Done inside the filter loop, that part would run once
+            // per loop trip in which any lane of the wave had a candidate.
+            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            int nc = 0;
+            auto settle = [&](uint32_t y) {
+                const CellBody by = g.body[y];
+                uint32_t py = by.idx;
+                int32_t ry = by.r;
+                uint64_t tk = pair_key(g, x, y);
+                vec2 X = versioned_pos(x, tk, cseg, adj, n_adj, hkeys, hsi, out, g.body);
+                vec2 Y = versioned_pos(y, tk, cseg, adj, n_adj, hkeys, hsi, out, g.body);
+                bool hit = (px < py) ? in_contact(X, Y, rx, ry) : in_contact(Y, X, ry, rx);
+                if (hit) {
+                    if (write_pass) out_keys[at + found] = tk;
+                    else if (found == 0) first_key[t] = tk;
+                    ++found;
+                }
+            };
             if (!skip_cell)
             for_each_slot_in_cell(g, x, which, [&](uint32_t y) {
                 const CellBody by = g.body[y];
@@ -1254,16 +1275,14 @@ struct ContactRetest {
                 double ddx = by.x - bx.x, ddy = by.y - bx.y;
                 if (ddx * ddx + ddy * ddy > reach * reach) return;
                 if (sy >= 0 && py < px) return;       // y's own pass emits it
-                uint64_t tk = pair_key(g, x, y);
-                vec2 X = versioned_pos(x, tk, cseg, adj, n_adj, hkeys, hsi, out, g.body);
-                vec2 Y = versioned_pos(y, tk, cseg, adj, n_adj, hkeys, hsi, out, g.body);
-                bool hit = (px < py) ? in_contact(X, Y, rx, ry) : in_contact(Y, X, ry, rx);
-                if (hit) {
-                    if (write_pass) out_keys[at + found] = tk;
-                    else if (found == 0) first_key[t] = tk;
-                    ++found;
-                }
+                if (nc == 0) c0 = y; else if (nc == 1) c1 = y; else if (nc == 2) c2 = y; else if (nc == 3) c3 = y;
+                else settle(y);                       // more than four near neighbours in one cell: rare
+                ++nc;
             });
+            if (nc > 0) settle(c0);
+            if (nc > 1) settle(c1);
+            if (nc > 2) settle(c2);
+            if (nc > 3) settle(c3);
         }
         if (!write_pass) counts[t] = found;
     }
