@@ -1197,8 +1197,8 @@ struct SegDisplacement {
 // different lanes; 20 n_H elements, fewer than 2^32); only the first entry of a
 // slot's segment works.  A pair of
 // two touched slots is emitted once, by the slot whose particle index is lower.
-// Two passes around a scan, like ContactDetect: counts[t] and the first hit's key,
-// then keys at offsets[t] (elements with two or more hits redo their tests).
+// Two passes around a scan, like ContactDetect: counts[t] and the first two hits'
+// keys, then keys at offsets[t] (elements with three or more hits redo their tests).
 struct ContactRetest {
     int64_t n_adj;
     GridView g;
@@ -1216,7 +1216,7 @@ struct ContactRetest {
     const uint32_t* dmax_bits;
     uint32_t* counts;
     const uint32_t* offsets;
-    uint64_t* first_key;       // count pass: key of an element's first hit
+    uint64_t* first_key;       // count pass: keys of an element's first and second hit, [2t] and [2t + 1]
     uint64_t* out_keys;
     int32_t write_pass;
     PSIM_HD void operator()(int64_t t) const
@@ -1224,7 +1224,11 @@ struct ContactRetest {
         if (write_pass) {
             uint32_t c = counts[t];
             if (c == 0) return;
-            if (c == 1) { out_keys[offsets[t]] = first_key[t]; return; }
+            if (c <= 2) {
+                out_keys[offsets[t]] = first_key[2 * t];
+                if (c == 2) out_keys[offsets[t] + 1] = first_key[2 * t + 1];
+                return;
+            }
         }
         // element = cell selector * n_adj + adjacency entry: the lanes of a wave look at the same
         // one of the nine cells for 64 consecutive entries, so they run loops of similar length
@@ -1259,7 +1263,7 @@ struct ContactRetest {
                 bool hit = (px < py) ? in_contact(X, Y, rx, ry) : in_contact(Y, X, ry, rx);
                 if (hit) {
                     if (write_pass) out_keys[at + found] = tk;
-                    else if (found == 0) first_key[t] = tk;
+                    else if (found < 2) first_key[2 * t + found] = tk;
                     ++found;
                 }
             };
