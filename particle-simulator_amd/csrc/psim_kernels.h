@@ -930,15 +930,26 @@ struct AdjLinks {
     int32_t* cseg;       // slot -> first adjacency entry (-1 = clean)
     int32_t* prev;       // [2h + side]
     uint32_t* zero_word; // cleared here: SegDisplacement raises it to the largest displacement bound
+    uint32_t* is_first;  // [e] 1 for the first entry of a slot's segment (compacted into a list afterwards)
     PSIM_HD void operator()(int64_t e) const
     {
         if (e == 0) *zero_word = 0u;
         uint32_t slot = (uint32_t)(adj[e] >> 32), h = (uint32_t)adj[e];
         bool first = (e == 0) || ((uint32_t)(adj[e - 1] >> 32) != slot);
+        is_first[e] = first ? 1u : 0u;
         if (first) cseg[slot] = (int32_t)e;
         int side = (hsi[h] == slot) ? 0 : 1;
         prev[2 * h + side] = first ? -1 : (int32_t)(uint32_t)adj[e - 1];
     }
+};
+
+// list of the first entries of the segments (= one entry per touched slot), from the scan of is_first
+struct CompactFirst {
+    int64_t n;
+    const uint32_t* is_first;
+    const uint32_t* pos;
+    uint32_t* list;
+    PSIM_HD void operator()(int64_t e) const { if (is_first[e]) list[pos[e]] = (uint32_t)e; }
 };
 
 // particle_system.py:200-268 (_resolve_collision_jit), strict FP64, in two halves.
@@ -1193,9 +1204,9 @@ struct SegDisplacement {
 
 // Re-test, against the versioned positions, every candidate pair that involves
 // a slot touched by a hypothesised contact.  Element index = cell selector *
-// n_adj + adjacency entry (the nine cells of one touched slot are re-tested by
-// different lanes; 20 n_H elements, fewer than 2^32); only the first entry of a
-// slot's segment works.  A pair of
+// n_adj + index into the list of touched slots (the nine cells of one touched slot
+// are re-tested by different lanes; the launch covers 20 n_H elements, fewer than
+// 2^32, of which those past the end of the list have nothing to do).  A pair of
 // two touched slots is emitted once, by the slot whose particle index is lower.
 // Two passes around a scan, like ContactDetect: counts[t] and the first two hits'
 // keys, then keys at offsets[t] (elements with three or more hits redo their tests).
@@ -1214,6 +1225,8 @@ struct ContactRetest {
     int32_t prune, r_max;
     double cell_size;
     const uint32_t* dmax_bits;
+    const uint32_t* touched;   // the first adjacency entry of every touched slot
+    const uint32_t* n_touched;
     uint32_t* counts;
     const uint32_t* offsets;
     uint64_t* first_key;       // count pass: keys of an element's first and second hit, [2t] and [2t + 1]
@@ -1230,15 +1243,16 @@ struct ContactRetest {
                 return;
             }
         }
-        // element = cell selector * n_adj + adjacency entry: the lanes of a wave look at the same
-        // one of the nine cells for 64 consecutive entries, so they run loops of similar length
+        // element = cell selector * n_adj + touched-slot number: the lanes of a wave look at the same
+        // one of the nine cells for 64 consecutive touched slots, so they run loops of similar length
         // (and a wave whose cell is out of reach for all of them ends at once)
         const uint32_t which_u = (uint32_t)t / (uint32_t)n_adj;
-        int64_t e = t - (int64_t)which_u * n_adj;
+        const int64_t ti = t - (int64_t)which_u * n_adj;
         int which = (int)which_u;
-        uint32_t x = (uint32_t)(adj[e] >> 32);
         uint32_t found = 0;
-        if (cseg[x] == (int32_t)e) {
+        if (ti < (int64_t)*n_touched) {
+            const int64_t e = touched[ti];
+            const uint32_t x = (uint32_t)(adj[e] >> 32);
             const CellBody bx = g.body[x];
             uint32_t px = bx.idx;
             int32_t rx = bx.r;

@@ -120,6 +120,7 @@ public:
     size_t ccap = 0;
     DevBuf<uint64_t> h0[2], hc[2], hn[2], adj[2];
     DevBuf<uint32_t> hsi, hsj, done, pcount, poffs, moved_list;
+    DevBuf<uint32_t> tflag, tpos, tlist;     // touched slots of the current hypothesis (flags, scan, list of first entries)
     DevBuf<uint64_t> first_key;
     DevBuf<uint8_t> moved;
     DevBuf<double> cdelta;
@@ -546,6 +547,7 @@ public:
         for (int i = 0; i < 2; ++i) { h0[i].ensure(c); hc[i].ensure(c); hn[i].ensure(c); adj[i].ensure(2 * c); }
         hsi.ensure(c); hsj.ensure(c); done.ensure(c); prevl.ensure(2 * c); outp.ensure(2 * c); outv.ensure(2 * c);
         cgeo.ensure(3 * c); cvals.ensure(3 * c);
+        tflag.ensure(2 * c); tpos.ensure(2 * c); tlist.ensure(2 * c);
         sum_pe.ensure(c); sum_ke.ensure(c); sum_heat.ensure(c);
         ln.sort_tmp->ensure(be::sort_temp_words(2 * c));
         ccap = c;
@@ -688,7 +690,10 @@ public:
             // field alone leaves each slot's contacts in order
             int sa = be::radix_sort_pairs<uint64_t>(ln.s, ka, nullptr, 2ull * nH, 32, 32 + slot_field_bits, ln.sort_tmp->p);
             adjs = adj[sa].p;
-            be::launch(ln.s, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p, ctr + 7});
+            be::launch(ln.s, 2ll * nH, AdjLinks{2ll * nH, adjs, hsi.p, cseg.p, prevl.p, ctr + 7, tflag.p});
+            scan_scratch.ensure_zero(ln.s, be::scan_temp_words(2ull * nH));
+            be::exclusive_scan_u32(ln.s, tflag.p, tpos.p, 2ull * nH, scan_scratch.p, ctr + 8, ln.small_groups);
+            be::launch(ln.s, 2ll * nH, CompactFirst{2ll * nH, tflag.p, tpos.p, tlist.p});
             // Dependency rounds.  A first batch is launched without asking how far it got (a
             // round with nothing ready is a no-op); whether contacts are still pending is read
             // back together with the re-test count below, and only then are more rounds run.
@@ -721,6 +726,7 @@ public:
                 r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outp.p;
                 r.dseg = dseg.p;
                 r.prune = sweep == 0 ? 1 : 0; r.r_max = max_radius; r.cell_size = (double)cfg.cell_size; r.dmax_bits = ctr + 7;
+                r.touched = tlist.p; r.n_touched = ctr + 8;
                 r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
                 rp.carry = ContactCarryClean{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
