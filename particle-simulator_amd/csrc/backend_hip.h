@@ -72,6 +72,14 @@ inline Event event_create()
 inline void event_destroy(Event e) { if (e) (void)hipEventDestroy(e); }
 inline void event_record(Event e, Stream s) { PSIM_HIP(hipEventRecord(e, s)); }
 inline void stream_wait(Stream s, Event e) { PSIM_HIP(hipStreamWaitEvent(s, e, 0)); }
+// has everything submitted before the event's record finished? (no waiting)
+inline bool event_done(Event e)
+{
+    hipError_t r = hipEventQuery(e);
+    if (r == hipSuccess) return true;
+    if (r != hipErrorNotReady) check(r, "hipEventQuery");
+    return false;
+}
 // page-locked host memory: small device-to-host readbacks land here without a staging copy
 inline void* host_alloc_pinned(size_t bytes)
 {
