@@ -156,6 +156,28 @@ def clustered_state(n, bounds, seed, clusters, per, spread):
     return dict(positions=pos[perm], masses=masses[perm], temperatures=temps[perm])
 
 
+def out_of_bounds_state(n, bounds, seed, outside):
+    """dense uniform particles, `outside` of them moved up to 30 px beyond the four edges
+    (walls only act at the end of a step, so a drifted particle can sit outside
+    the box when the grid is built: the grid clips it into an edge cell, whose region is
+    therefore unbounded outwards), each next to an in-bounds partner it overlaps"""
+    rng = np.random.default_rng(seed)
+    b = np.array(bounds, dtype=np.float64)
+    pos = rng.random((n, 2)) * b
+    for k in range(outside):
+        side = k % 4
+        t = 0.02 + 0.96 * rng.random()
+        d = 1.0 + rng.random() * 29.0
+        # (not beyond a corner: two particles outside both ranges share all 32 quadtree levels,
+        # which the reference's insertion does not survive)
+        edge = [(-d, t * b[1]), (b[0] + d, t * b[1]), (t * b[0], -d), (t * b[0], b[1] + d)][side]
+        pos[2 * k] = edge
+        pos[2 * k + 1] = np.array(edge) + rng.normal(0.0, 1.5, 2)      # overlapping partner, maybe inside, maybe not
+    perm = rng.permutation(n)
+    return dict(positions=pos[perm], masses=rng.uniform(5.0, 20.0, (n, 1))[perm],
+                temperatures=rng.uniform(0.05, 0.1, (n, 1))[perm])
+
+
 def gaussian_cluster_state(n, bounds, sigma, seed, temp_lo=0.3, temp_hi=0.9):
     """one Gaussian blob about the centre (dense-core stress: many
     particles per grid cell, long contact chains, many solver rounds)"""

@@ -129,6 +129,15 @@ def test_side_stream_on_and_off_give_identical_states():
     b.close()
 
 
+@pytest.mark.parametrize("walls", [True, False])
+def test_particles_outside_the_box_vs_oracle(walls):
+    """contacts among particles the grid clips into its edge cells: the re-test's skipping of
+    out-of-reach neighbour cells must treat those cells as unbounded"""
+    n, bounds = 20000, (2600, 1800)
+    st = parity.out_of_bounds_state(n, bounds, 11, 1500)
+    parity.run_against_oracle(n, SIM, 1, bounds, 3, HIP, state=st, stage_mask=31 if walls else 31 - 8)
+
+
 def test_walk_variants_agree_and_counts():
     g = load_golden("tree20k")
     a = parity.make_system(g, HIP, walk_mode=0)

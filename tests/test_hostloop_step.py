@@ -63,6 +63,16 @@ def test_two_collision_sweeps_hot_start_vs_oracle():
     parity.run_against_oracle(2500, sim, 6, (1060, 600), 3, HOSTLOOP, walk_mode=1)
 
 
+@pytest.mark.parametrize("walls", [True, False])
+def test_particles_outside_the_box_vs_oracle(walls):
+    """contacts among particles the grid clips into its edge cells (with the walls stage off they
+    stay outside for every step): the re-test's skipping of out-of-reach neighbour cells
+    must treat those cells as unbounded"""
+    n, bounds = 1500, (700, 500)
+    st = parity.out_of_bounds_state(n, bounds, 11, 120)
+    parity.run_against_oracle(n, SIM, 1, bounds, 3, HOSTLOOP, walk_mode=1, state=st, stage_mask=31 if walls else 31 - 8)
+
+
 @pytest.mark.parametrize("mask", [0, 2 | 4 | 8, 1 | 8, 31 - 2])
 def test_stage_masks_vs_oracle(mask):
     """stage switches (the reference has none; the oracle mirrors them): gravity only;
