@@ -822,6 +822,12 @@ struct ContactDetect {
     int32_t write_pass;
     uint32_t* cand_counter;    // optional (pass 0): number of candidate pairs
     uint32_t* coincident_counter;   // pass 0: pairs at squared distance exactly 0
+    // prune: the positions are the ones the grid was built from, so a forward cell is only
+    // fetched when the slot lies within contact distance (its radius + the largest radius
+    // r_max) of the border it shares with that cell; the candidate count is the reference's
+    // all the same (it is a sum of cell populations)
+    int32_t prune, r_max;
+    double cell_size;
     // Every unordered candidate pair is examined once: in-cell pairs from the earlier
     // slot, cross-cell pairs from the cell that has the other one among its four
     // "forward" neighbours (E, SW, S, SE).  A contact is keyed from its lower-index
@@ -838,17 +844,30 @@ struct ContactDetect {
         const int32_t mr = me.r;
         const int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
         const bool east = cx + 1 < g.gw, west = cx > 0, south = cy + 1 < g.gh;
-        const int32_t a_hi = g.offsets[c + (east ? 2u : 1u)];
-        int32_t b_lo = 0, b_hi = 0;
-        if (south) {
-            const uint32_t s = c + (uint32_t)g.gw;
-            b_lo = g.offsets[s - (west ? 1u : 0u)];
-            b_hi = g.offsets[s + (east ? 2u : 1u)];
+        // Every position the grid puts into column cx + 1 or beyond has x >= (cx + 1) cell_size,
+        // into row cy + 1 or beyond y >= (cy + 1) cell_size, into column cx - 1 or before
+        // x < cx cell_size (particle_system.py:744-749; clipping only moves positions outwards).
+        // The comparisons are written so that a NaN coordinate keeps the cell.
+        bool need_e = east, need_s = south, need_sw = south && west, need_se = south && east;
+        if (prune) {
+            const double reach = (double)(mr + r_max) + 1e-6;
+            const double gap_e = (double)(cx + 1) * cell_size - px, gap_s = (double)(cy + 1) * cell_size - py;
+            const double gap_w = px - (double)cx * cell_size;
+            need_e = need_e && !(gap_e > reach);
+            need_s = need_s && !(gap_s > reach);
+            need_sw = need_sw && need_s && !(gap_w > reach);
+            need_se = need_se && need_s && !(gap_e > reach);
         }
-        uint32_t ncand = 0, found = 0;
+        const int32_t a_hi = g.offsets[c + (need_e ? 2u : 1u)];
+        int32_t b_lo = 0, b_hi = 0;
+        if (need_s) {
+            const uint32_t s = c + (uint32_t)g.gw;
+            b_lo = g.offsets[s - (need_sw ? 1u : 0u)];
+            b_hi = g.offsets[s + (need_se ? 2u : 1u)];
+        }
+        uint32_t found = 0;
         const uint32_t at = WRITE ? offsets[k] : 0u;
         auto visit = [&](const CellBody& o, int32_t b) {
-            ++ncand;
             // particle_system.py:210-217; the squared distance does not depend on which
             // of the two is "i" (the differences only change sign)
             double dx = o.x - px, dy = o.y - py;
@@ -879,7 +898,15 @@ struct ContactDetect {
         sweep(b_lo, b_hi);
         if (!WRITE) {
             counts[k] = found;
-            if (cand_counter && ncand) atomic_inc_u32(cand_counter, ncand);
+            if (cand_counter) {
+                // particle_system.py:156-197 visits every slot after k in its cell and every slot of the forward cells
+                int32_t nc = g.offsets[c + (east ? 2u : 1u)] - ((int32_t)k + 1);
+                if (south) {
+                    const uint32_t s = c + (uint32_t)g.gw;
+                    nc += g.offsets[s + (east ? 2u : 1u)] - g.offsets[s - (west ? 1u : 0u)];
+                }
+                if (nc > 0) atomic_inc_u32(cand_counter, (uint32_t)nc);
+            }
         }
     }
     PSIM_HD void operator()(int64_t kk) const

@@ -434,6 +434,7 @@ public:
         pcount.ensure(c); poffs.ensure(c); first_key.ensure(c); scan_scratch.ensure_zero(s, be::scan_temp_words(c));
         be::dev_memset(s, ctr, 0, 64);
         ContactDetect d;
+        d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
         d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
         d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? ctr + 1 : nullptr;
         d.coincident_counter = ctr + 3;
@@ -632,8 +633,13 @@ public:
     bool ext_given = false;
     int64_t ext_n0 = 0, ext_candidates = 0, ext_coincident = 0;
 
+    // ContactDetect may skip forward cells by distance to the shared border only while the
+    // slot records hold the positions the grid was built from (the step's first sweep)
+    bool detect_prune = true;
+
     void sweep_positions(const Lane& ln, int sweep)
     {
+        if (sweep > 0) detect_prune = false;
         GridView g = grid_view();
         const int slot_field_bits = ceil_log2_u64((uint64_t)n + 1);
         uint32_t* const ctr = ln.ctr;
@@ -665,6 +671,7 @@ public:
                 detect_count(ln.s, scan_scratch, ctr, ln.small_groups);
             }
             ContactDetect d;
+            d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
             d.n = n; d.k0 = 0; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
             d.coincident_counter = nullptr;
             uint32_t three[4];
@@ -1093,6 +1100,7 @@ public:
         cond_ne = 0;
         totals_pending = false;
         walk_in_flight = false;
+        detect_prune = true;
     }
     void no_collisions()
     {
@@ -1192,6 +1200,7 @@ public:
         if (four[0] > 0 && (int64_t)four[0] <= cap && k_hi > k_lo) {
             GridView g = grid_view();
             ContactDetect d;
+            d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
             d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
             d.first_pair = first_key.p; d.coincident_counter = nullptr; d.cand_counter = nullptr;
             d.out_keys = keys_out; d.write_pass = 1;
