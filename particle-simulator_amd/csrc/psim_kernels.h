@@ -1234,7 +1234,7 @@ struct SegDisplacement {
 // n_adj + index into the list of touched slots (the nine cells of one touched slot
 // are re-tested by different lanes; the launch covers 20 n_H elements, fewer than
 // 2^32, of which those past the end of the list have nothing to do).  A pair of
-// two touched slots is emitted once, by the slot whose particle index is lower.
+// two touched slots is emitted once, by the lower slot.
 // Two passes around a scan, like ContactDetect: counts[t] and the first two hits'
 // keys, then keys at offsets[t] (elements with three or more hits redo their tests).
 struct ContactRetest {
@@ -1310,16 +1310,15 @@ struct ContactRetest {
             };
             if (!skip_cell)
             for_each_slot_in_cell(g, x, which, [&](uint32_t y) {
-                const CellBody by = g.body[y];
-                uint32_t py = by.idx;
-                int32_t ry = by.r;
                 int32_t sy = cseg[y];
+                if (sy >= 0 && y < x) return;         // two touched slots: the lower slot's pass emits the pair
+                const CellBody by = g.body[y];
+                int32_t ry = by.r;
                 // no version of x and y can touch if their initial positions are further
                 // apart than the contact distance plus both displacement bounds
                 double reach = (double)(rx + ry) + reach_x + (sy >= 0 ? dseg[sy] : 0.0);
                 double ddx = by.x - bx.x, ddy = by.y - bx.y;
                 if (ddx * ddx + ddy * ddy > reach * reach) return;
-                if (sy >= 0 && py < px) return;       // y's own pass emits it
                 if (nc == 0) c0 = y; else if (nc == 1) c1 = y; else if (nc == 2) c2 = y; else if (nc == 3) c3 = y;
                 else settle(y);                       // more than four near neighbours in one cell: rare
                 ++nc;

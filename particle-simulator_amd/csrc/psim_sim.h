@@ -648,7 +648,6 @@ public:
         // ---- sweep against the initial positions (count, scan, write)
         uint32_t n0 = 0, cand = 0;
         int key_bits = 64;
-        const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
         if (sweep == 0 && ext_given) {
             // the initial sweep's contact keys were detected elsewhere (slabs of slots on several
             // ranks, gathered by the caller): take them as they are
