@@ -6,7 +6,8 @@ usage: hbm_table.py TRACE_DB [FETCH_DB [WRITE_DB]] [--n PARTICLES]
 TRACE_DB: rocprofv3 --kernel-trace --output-format rocpd run of `bench.py --no-overlap`
 (every stage on one stream, so durations are not stretched by the walk).  FETCH_DB /
 WRITE_DB: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of the same command.
-Algorithmic bytes per particle are the figures of DESIGN.md section 4.  Counter values are
+Algorithmic bytes per particle are listed in ROWS below (state arrays read and written by
+each kernel, FP64 positions as 16-byte pairs).  Counter values are
 printed raw (KiB as rocprofv3 reports them -> bytes); on gfx950 FETCH_SIZE reads half the
 bytes of a wide coalesced stream and is uncalibrated for narrower or scattered accesses."""
 import re
