@@ -1235,8 +1235,9 @@ struct SegDisplacement {
 // are re-tested by different lanes; the launch covers 20 n_H elements, fewer than
 // 2^32, of which those past the end of the list have nothing to do).  A pair of
 // two touched slots is emitted once, by the lower slot.
-// Two passes around a scan, like ContactDetect: counts[t] and the first two hits'
-// keys, then keys at offsets[t] (elements with three or more hits redo their tests).
+// Two passes around a scan, like ContactDetect: counts[t] and the first kRetestKept hits'
+// keys, then keys at offsets[t] (elements with more hits than that redo their tests).
+constexpr int kRetestKept = 4;
 struct ContactRetest {
     int64_t n_adj;
     GridView g;
@@ -1256,7 +1257,7 @@ struct ContactRetest {
     const uint32_t* n_touched;
     uint32_t* counts;
     const uint32_t* offsets;
-    uint64_t* first_key;       // count pass: keys of an element's first and second hit, [2t] and [2t + 1]
+    uint64_t* first_key;       // count pass: keys of an element's first kRetestKept hits, from [kRetestKept t] on
     uint64_t* out_keys;
     int32_t write_pass;
     PSIM_HD void operator()(int64_t t) const
@@ -1264,9 +1265,8 @@ struct ContactRetest {
         if (write_pass) {
             uint32_t c = counts[t];
             if (c == 0) return;
-            if (c <= 2) {
-                out_keys[offsets[t]] = first_key[2 * t];
-                if (c == 2) out_keys[offsets[t] + 1] = first_key[2 * t + 1];
+            if (c <= (uint32_t)kRetestKept) {
+                for (uint32_t i = 0; i < c; ++i) out_keys[offsets[t] + i] = first_key[(int64_t)kRetestKept * t + i];
                 return;
             }
         }
@@ -1304,7 +1304,7 @@ struct ContactRetest {
                 bool hit = (px < py) ? in_contact(X, Y, rx, ry) : in_contact(Y, X, ry, rx);
                 if (hit) {
                     if (write_pass) out_keys[at + found] = tk;
-                    else if (found < 2) first_key[2 * t + found] = tk;
+                    else if (found < (uint32_t)kRetestKept) first_key[(int64_t)kRetestKept * t + found] = tk;
                     ++found;
                 }
             };

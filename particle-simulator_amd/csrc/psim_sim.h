@@ -734,7 +734,7 @@ public:
             {
                 int64_t nt = 20ll * nH, ntot = nt + n0;
                 if (nt >= (1ll << 32)) throw std::runtime_error("psim: too many contacts for one sweep");
-                pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure(2 * (size_t)nt);
+                pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)kRetestKept * (size_t)nt);
                 scan_scratch.ensure_zero(ln.s, be::scan_temp_words((uint64_t)ntot));
                 dseg.ensure(2 * (size_t)nH);
                 be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1});
