@@ -44,7 +44,10 @@ inline void raise_to_u32(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
 #else
 __device__ __forceinline__ void raise_to_u32(uint32_t* p, uint32_t v)
 {
-    if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
+    // a plain (cacheable, possibly stale) look first: most lanes stop there
+    if (v > *reinterpret_cast<volatile uint32_t*>(p) &&
+        v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(p, v);
 }
 #endif
 
@@ -807,17 +810,19 @@ PSIM_HD PSIM_FORCEINLINE void sweep_slots4(const CellBody* PSIM_RESTRICT body, c
 // Sweep 0: test every candidate pair against the sweep's initial positions and
 // collect the keys of those in contact (unordered between lanes; sorted
 // afterwards).  Two passes around an exclusive scan instead of an atomic
-// cursor: pass 0 stores how many contacts each slot found and the first one's
-// two slots; pass 1 writes that pair's key at its scanned offset, and only the
-// slots that found two or more redo their tests.
+// cursor: pass 0 stores how many contacts each slot found and the partner slots of
+// the first kDetectKept; pass 1 writes those pairs' keys from the slot's scanned
+// offset on, and only the slots that found more redo their tests.
+constexpr int kDetectKept = 4;
 struct ContactDetect {
     int64_t n;                 // slots [k0, k0 + n) are swept
     uint32_t k0;
     GridView g;
     uint32_t* counts;          // pass 0: written; pass 1: read
     const uint32_t* offsets;   // pass 1: exclusive scan of counts
-    uint64_t* first_pair;      // pass 0: the two slots of a slot's first contact (the key's field
-                               // widths are only known after pass 0); pass 1: read
+    uint32_t* first_pair;      // pass 0: the partner slots of a slot's first kDetectKept contacts, from
+                               // [kDetectKept k] on (the keys' field widths are only known after
+                               // pass 0); pass 1: read
     uint64_t* out_keys;        // pass 1
     int32_t write_pass;
     uint32_t* cand_counter;    // optional (pass 0): number of candidate pairs
@@ -875,7 +880,7 @@ struct ContactDetect {
             double md = (double)(mr + o.r);
             if (d2 < md * md && d2 > 0) {
                 if (WRITE) out_keys[at + found] = pair_key(g, k, (uint32_t)b);
-                else if (found == 0) first_pair[k] = ((uint64_t)k << 32) | (uint64_t)(uint32_t)b;
+                else if (found < (uint32_t)kDetectKept) first_pair[(size_t)kDetectKept * k + found] = (uint32_t)b;
                 ++found;
             } else if (!WRITE && d2 == 0) {
                 aggregated_inc(coincident_counter);
@@ -914,11 +919,11 @@ struct ContactDetect {
         const uint32_t k = k0 + (uint32_t)kk;
         if (write_pass) {
             uint32_t c = counts[k];
-            if (c == 1) {
-                uint64_t fp = first_pair[k];
-                out_keys[offsets[k]] = pair_key(g, (uint32_t)(fp >> 32), (uint32_t)fp);
-            } else if (c > 1) {
+            if (c > (uint32_t)kDetectKept) {
                 run<true>(k);
+            } else {
+                for (uint32_t i = 0; i < c; ++i)
+                    out_keys[offsets[k] + i] = pair_key(g, k, first_pair[(size_t)kDetectKept * k + i]);
             }
         } else {
             run<false>(k);

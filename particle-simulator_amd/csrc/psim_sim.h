@@ -431,11 +431,11 @@ public:
         if (k_hi < 0) k_hi = n;
         const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
         GridView g = grid_view();
-        pcount.ensure(c); poffs.ensure(c); first_key.ensure(c); scan_scratch.ensure_zero(s, be::scan_temp_words(c));
+        pcount.ensure(c); poffs.ensure(c); first_key.ensure((size_t)kDetectKept * c / 2 + 1); scan_scratch.ensure_zero(s, be::scan_temp_words(c));
         be::dev_memset(s, ctr, 0, 64);
         ContactDetect d;
         d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
-        d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
+        d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = reinterpret_cast<uint32_t*>(first_key.p);
         d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? ctr + 1 : nullptr;
         d.coincident_counter = ctr + 3;
         be::launch(s, k_hi - k_lo, d);
@@ -671,7 +671,7 @@ public:
             }
             ContactDetect d;
             d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
-            d.n = n; d.k0 = 0; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = first_key.p;
+            d.n = n; d.k0 = 0; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = reinterpret_cast<uint32_t*>(first_key.p);
             d.coincident_counter = nullptr;
             uint32_t three[4];
             readback_on(ln, three, dctr, 16);
@@ -1201,7 +1201,7 @@ public:
             ContactDetect d;
             d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
             d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
-            d.first_pair = first_key.p; d.coincident_counter = nullptr; d.cand_counter = nullptr;
+            d.first_pair = reinterpret_cast<uint32_t*>(first_key.p); d.coincident_counter = nullptr; d.cand_counter = nullptr;
             d.out_keys = keys_out; d.write_pass = 1;
             be::launch(ln.s, k_hi - k_lo, d);
             out4[3] = four[0];
