@@ -33,7 +33,12 @@ if dense_hot:
 else:
     side = float(np.sqrt(n / 1e-3))            # 1e-3 particles per square pixel, as config.json
     bounds = (side * np.sqrt(2.0), side / np.sqrt(2.0))
-    ps = ParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds)
+    sim = dict(SIM)
+    if len(sys.argv) > 3 and sys.argv[3] == "hot":
+        # a tenth of the particles start at or above the explosion threshold (1.0): mass
+        # explosions, compaction and the event log at scale
+        sim.update(min_temp=0.8, max_temp=1.022)
+    ps = ParticleSystem(n, sim, np.random.default_rng(42), bounds)
 print("init %.1f s" % (time.time() - t0), flush=True)
 m0 = float(ps.masses.sum())
 ps._calculate_gravity()
