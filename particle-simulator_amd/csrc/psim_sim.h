@@ -142,6 +142,8 @@ public:
     DevBuf<double> ex_energy, ex_total;
     DevBuf<uint64_t> ex_entries[2];
     size_t ecap = 0;
+    void* ex_stage = nullptr;        // page-locked staging for the explosion events
+    size_t ex_stage_cap = 0;
     std::vector<ExplosionEvent> events;
     std::vector<int32_t> last_exploded;
 
@@ -235,6 +237,7 @@ public:
         timer.destroy();
         be::mailbox_destroy(mailbox);
         be::mailbox_destroy(mailbox2);
+        be::host_free_pinned(ex_stage);
         be::event_destroy(ev_drift);
         be::event_destroy(ev_side);
         be::event_destroy(ev_walk);
@@ -1012,11 +1015,20 @@ public:
                                               ex_total.p, vel.p});
         }
         // events for the host-side log (particle_system.py:683-689)
-        std::vector<uint32_t> hl(count), hc2(count);
-        std::vector<double> he(count);
-        be::copy_d2h(st, hl.data(), ex_list.p, (size_t)count * 4);
-        be::copy_d2h(st, hc2.data(), ex_count.p, (size_t)count * 4);
-        be::copy_d2h(st, he.data(), ex_energy.p, (size_t)count * 8);
+        // (through page-locked memory: three copies in flight, one wait)
+        const size_t stage_bytes = (size_t)count * 16 + 64;
+        if (stage_bytes > ex_stage_cap) {
+            be::host_free_pinned(ex_stage);
+            ex_stage = nullptr; ex_stage_cap = 0;
+            ex_stage = be::host_alloc_pinned(stage_bytes + stage_bytes / 2);
+            ex_stage_cap = stage_bytes + stage_bytes / 2;
+        }
+        double* he = reinterpret_cast<double*>(ex_stage);
+        uint32_t* hl = reinterpret_cast<uint32_t*>(he + count);
+        uint32_t* hc2 = hl + count;
+        be::copy_d2h(st, hl, ex_list.p, (size_t)count * 4);
+        be::copy_d2h(st, hc2, ex_count.p, (size_t)count * 4);
+        be::copy_d2h(st, he, ex_energy.p, (size_t)count * 8);
         be::sync(st);
         last_exploded.resize(count);
         for (uint32_t i = 0; i < count; ++i) {
