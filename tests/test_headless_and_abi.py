@@ -71,6 +71,46 @@ def test_bad_arguments_are_value_errors():
     assert L.psim_step(None, 1) == -1
 
 
+def test_staged_entry_points_reject_bad_ranges_and_work_by_hand():
+    """the multi-GPU stage calls driven directly through the C ABI on one rank: bad ranges are
+    PSIM_ERR_INVALID, a key buffer that is too small reports the count and writes nothing, and
+    detection split over two slabs hands the solver the same contacts as one sweep"""
+    n, bounds = 600, (420, 300)
+    ref = ParticleSystem(n, dict(SIM), np.random.default_rng(4), bounds, library=HOSTLOOP, walk_mode=1, debug=True)
+    s = ParticleSystem(n, dict(SIM), np.random.default_rng(4), bounds, library=HOSTLOOP, walk_mode=1, debug=True)
+    ref._calculate_gravity(); s._calculate_gravity()
+    ref.update()
+    L, ctx = s._lib, s._ctx
+    acc = np.zeros((n, 2))
+    tmp = np.zeros(n)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    out = (ctypes.c_int64 * 4)()
+    assert L.psim_stage_build(ctx) == 0
+    assert L.psim_stage_gravity(ctx, 5, 3, vp(acc)) == -1              # lo > hi
+    assert L.psim_stage_gravity(ctx, 0, n, vp(acc)) == 0
+    keys = np.zeros(4096, dtype=np.uint64)
+    assert L.psim_stage_detect(ctx, 2, n, vp(keys), 4096, out) == -1   # lo not a multiple of 4
+    assert L.psim_stage_detect(ctx, 0, n + 1, vp(keys), 4096, out) == -1
+    assert L.psim_stage_detect(ctx, 0, 256, vp(keys), 0, out) == 0
+    first, cand_a, coin_a = out[0], out[1], out[2]
+    assert first > 0 and out[3] == 0                                   # no room: counted, nothing written
+    assert L.psim_stage_detect(ctx, 0, 256, vp(keys), 4096, out) == 0 and out[3] == first
+    rest = np.zeros(4096, dtype=np.uint64)
+    assert L.psim_stage_detect(ctx, 256, n, vp(rest), 4096, out) == 0
+    allk = np.concatenate([rest[: out[0]], keys[:first]])              # any order
+    assert L.psim_stage_settle_positions_from(ctx, vp(allk), len(allk), cand_a + out[1], coin_a + out[2]) == 0
+    assert L.psim_stage_kick_collide(ctx, vp(acc)) == 0
+    assert L.psim_stage_conduction(ctx, 0, n, vp(tmp)) == 0
+    assert L.psim_stage_finish(ctx, vp(tmp)) == 0
+    s._stale = True
+    assert s.counts() == ref.counts()
+    for name in ("positions", "velocities", "temperatures"):
+        np.testing.assert_array_equal(getattr(s, name), getattr(ref, name), err_msg=name)
+    ms = ctypes.c_double(0.0)
+    assert L.psim_time_walk(ctx, 0, 0.0, ctypes.byref(ms)) == -1      # reps < 1
+    assert L.psim_time_walk(ctx, 1, 9.0, ctypes.byref(ms)) == -1      # more slots than a SIMD has
+
+
 def test_empty_and_single_particle_systems():
     for n in (0, 1, 2):
         s = ParticleSystem(n, dict(SIM), np.random.default_rng(1), (200, 100), library=HOSTLOOP, walk_mode=1)
