@@ -231,7 +231,7 @@ def main():
                                   "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                                   "frac": tf / PEAK_FP64_VALU_TFLOPS}
             bs.close()
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (one rank only: the other ranks would wait at the barrier)
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
