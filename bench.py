@@ -186,6 +186,10 @@ def main():
         # visits summed over particles, both counted on the current tree.
         visits, inter = ps.walk_counts()
         flops = 20.0 * inter + 8.0 * (visits - inter)
+        if world > 1:
+            # a rank's launch walks 1/world of the (Morton-sorted) targets: per-GPU figure,
+            # taking the ranks' shares of the work as equal
+            flops /= world
         walk_ms = stage_ms.get("gravity", 0.0)
         achieved = flops / (walk_ms * 1e-3) / 1e12 if walk_ms > 0 else 0.0
         counts = ps.counts()
