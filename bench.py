@@ -221,6 +221,12 @@ def main():
                           "solver_rounds": counts["solver_rounds"], "tree_nodes": counts["tree_nodes"],
                           "particles": counts["particles"]},
         }
+        if wl == "c2" and world == 1:
+            # recorded, not measured by this run: counters need rocprofv3 passes of their own
+            out["roofline"]["traffic_recorded"] = {
+                "fetch_bytes": 2.69e9, "write_bytes": 1.35e8, "algorithmic_bytes": 4.4e8,
+                "source": "profiles/r1_walk_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                          "raw counters; 32-byte scalar fetches are not a calibrated pattern on gfx950)"}
         if alone_ms:
             tf = flops / (alone_ms * 1e-3) / 1e12
             out["roofline"]["device_to_itself"] = {"kernel_ms": alone_ms, "achieved": tf, "frac": tf / PEAK_FP64_VALU_TFLOPS}
