@@ -1738,49 +1738,78 @@ struct ExplosionGather {
     GridView g;
     double cell_size;
     const vec2* pos;
-    const double* mass;
-    const double* temp;
     const uint8_t* boom;
-    double efficiency;
-    double* ex_energy;
-    double* ex_total_w;
-    uint32_t* ex_count;        // pass 0: written; pass 1: read
+    double* cell_w;            // pass 0: [9 r + cell] sum of the weights of that cell's neighbours
+    uint32_t* cell_count;      // pass 0: [9 r + cell] their number; pass 1: read
+    const uint32_t* cell_at;   // pass 1: [9 r + cell] where that cell's entries start inside the exploder's run
     const uint32_t* offsets;   // pass 1: exclusive scan of ex_count
     uint64_t* entries;         // pass 1
     int32_t write_pass;
-    PSIM_HD void operator()(int64_t r) const
+    // element = 9 * exploder rank + cell of the 3x3 neighbourhood in (dy, dx) order: the nine
+    // cells of one exploding particle are gathered by nine lanes
+    PSIM_HD void operator()(int64_t i) const
     {
+        const int64_t r = i / 9;
+        const int which = (int)(i - r * 9);
+        const int dy = which / 3 - 1, dx = which % 3 - 1;
         uint32_t p = list[r];
         vec2 P = pos[p];
         int64_t cx = (int64_t)(P.x / cell_size), cy = (int64_t)(P.y / cell_size);
         double total = 0.0;
         uint32_t cnt = 0;
-        uint32_t at = write_pass ? offsets[r] : 0u;
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                int64_t x = cx + dx, y = cy + dy;
-                if (x < 0 || x >= g.gw || y < 0 || y >= g.gh) continue;
-                int64_t c = y * g.gw + x;
-                for (int32_t k = g.offsets[c]; k < g.offsets[c + 1]; ++k) {
-                    uint32_t q = g.body[k].idx;
-                    if (q == p || boom[q]) continue;
-                    if (write_pass) {
-                        entries[at + cnt] = ((uint64_t)q << 32) | (uint64_t)r;
-                    } else {
-                        vec2 Q = pos[q];
-                        double ddx = Q.x - P.x, ddy = Q.y - P.y;
-                        double d2 = ddx * ddx + ddy * ddy;
-                        if (d2 == 0) d2 = 1e-6;
-                        total += 1.0 / d2;
-                    }
-                    ++cnt;
+        int64_t x = cx + dx, y = cy + dy;
+        if (!(x < 0 || x >= g.gw || y < 0 || y >= g.gh)) {
+            uint32_t at = write_pass ? offsets[r] + cell_at[i] : 0u;
+            int64_t c = y * g.gw + x;
+            for (int32_t k = g.offsets[c]; k < g.offsets[c + 1]; ++k) {
+                uint32_t q = g.body[k].idx;
+                if (q == p || boom[q]) continue;
+                if (write_pass) {
+                    entries[at + cnt] = ((uint64_t)q << 32) | (uint64_t)r;
+                } else {
+                    vec2 Q = pos[q];
+                    double ddx = Q.x - P.x, ddy = Q.y - P.y;
+                    double d2 = ddx * ddx + ddy * ddy;
+                    if (d2 == 0) d2 = 1e-6;
+                    total += 1.0 / d2;
                 }
+                ++cnt;
             }
-        if (!write_pass) {
-            ex_energy[r] = (mass[p] * temp[p]) * efficiency;
-            ex_total_w[r] = total;
-            ex_count[r] = cnt;
         }
+        if (!write_pass) {
+            cell_w[i] = total;
+            cell_count[i] = cnt;
+        }
+    }
+};
+
+// per exploding particle: the nine cells' sums and counts folded in cell order
+// (particle_system.py:664-700: energy, neighbour count, total weight)
+struct ExplosionCombine {
+    int64_t n_ex;
+    const uint32_t* list;
+    const double* mass;
+    const double* temp;
+    double efficiency;
+    const double* cell_w;
+    const uint32_t* cell_count;
+    uint32_t* cell_at;
+    double* ex_energy;
+    double* ex_total_w;
+    uint32_t* ex_count;
+    PSIM_HD void operator()(int64_t r) const
+    {
+        uint32_t p = list[r];
+        double total = 0.0;
+        uint32_t cnt = 0;
+        for (int c = 0; c < 9; ++c) {
+            cell_at[9 * r + c] = cnt;
+            total += cell_w[9 * r + c];
+            cnt += cell_count[9 * r + c];
+        }
+        ex_energy[r] = (mass[p] * temp[p]) * efficiency;
+        ex_total_w[r] = total;
+        ex_count[r] = cnt;
     }
 };
 

@@ -139,7 +139,8 @@ public:
     // explosions
     DevBuf<uint8_t> boom;
     DevBuf<uint32_t> tmp32, tmp32b, ex_list, ex_count, ex_offs;
-    DevBuf<double> ex_energy, ex_total;
+    DevBuf<double> ex_energy, ex_total, ex_cell_w;
+    DevBuf<uint32_t> ex_cell_count, ex_cell_at;
     DevBuf<uint64_t> ex_entries[2];
     size_t ecap = 0;
     void* ex_stage = nullptr;        // page-locked staging for the explosion events
@@ -991,18 +992,20 @@ public:
         uint32_t ne = 0;
         {
             ExplosionGather k;
+            ex_cell_w.ensure(9 * (size_t)count); ex_cell_count.ensure(9 * (size_t)count); ex_cell_at.ensure(9 * (size_t)count);
             k.n_ex = count; k.list = ex_list.p; k.g = g; k.cell_size = (double)cfg.cell_size; k.pos = pos.p;
-            k.mass = mass.p; k.temp = temp.p; k.boom = boom.p; k.efficiency = cfg.explosion_eff;
-            k.ex_energy = ex_energy.p; k.ex_total_w = ex_total.p; k.ex_count = ex_count.p;
+            k.boom = boom.p; k.cell_w = ex_cell_w.p; k.cell_count = ex_cell_count.p; k.cell_at = ex_cell_at.p;
             ex_offs.ensure(count);
             k.offsets = ex_offs.p; k.entries = nullptr; k.write_pass = 0;
-            be::launch(st, count, k);
+            be::launch(st, 9ll * count, k);
+            be::launch(st, count, ExplosionCombine{(int64_t)count, ex_list.p, mass.p, temp.p, cfg.explosion_eff, ex_cell_w.p,
+                                                   ex_cell_count.p, ex_cell_at.p, ex_energy.p, ex_total.p, ex_count.p});
             be::exclusive_scan_u32(st, ex_count.p, ex_offs.p, (uint64_t)count, scan_tmp.p, counters.p);
             ne = read_u32(counters.p);
             if (ne > 0) {
                 if (ne > ecap) { ecap = (size_t)ne + ne / 4 + 1024; ex_entries[0].ensure(ecap); ex_entries[1].ensure(ecap); }
                 k.entries = ex_entries[0].p; k.write_pass = 1;
-                be::launch(st, count, k);
+                be::launch(st, 9ll * count, k);
             }
         }
         if (ne > 0) {
