@@ -8,7 +8,10 @@ default density), state drawn exactly like the reference's __init__ with seed
 42, every stage on (gravity + collisions + conduction + cooling + walls +
 explosions).  N > 1: workload C3 (16,777,216-particle rotating disk), ONE
 simulation sharded over the N ranks, one process per GPU (torch.distributed /
-RCCL).
+RCCL).  `--gpus N` without a launcher's WORLD_SIZE in the environment starts the N rank
+processes itself (fresh children, started before anything touches the GPU; rank r on
+cuda:r) and passes rank 0's JSON line through; under torchrun (WORLD_SIZE set) the
+process is one rank of the launcher's job.
 
 A "step" is one ParticleSystem.update().  The timed region starts with the
 state resident in HBM; value = sum over timed steps of alive particles / wall
@@ -54,8 +57,8 @@ def disk_state(n, bounds, radius, rng, rotating=False, g_const=0.01):
     return st
 
 
-def workload(name):
-    """-> (label, n, bounds, state-or-None, stage_mask, seed)"""
+def workload(name, n=None):
+    """-> (label, n, bounds, state-or-None, stage_mask).  n: other size for the c4 recipe."""
     rng = np.random.default_rng(42)
     if name == "c0":
         return "C0 default config.json: 2000 particles, 2000x1000, all stages", 2000, (2000, 1000), None, 31
@@ -70,29 +73,68 @@ def workload(name):
         n, b = 1 << 24, (150000, 150000)
         return ("C3 16Mi rotating disk R=73078, all stages", n, b,
                 disk_state(n, b, 73078.0, rng, rotating=True), 31)
+    if name == "c4":
+        # dense stress case: uniform disk at 4x the default density, at rest, temperatures
+        # U[0.5, 0.9] so that collision heating pushes particles past the explosion threshold
+        # (64 Mi particles: R = 73078 in 150000 x 150000; other sizes keep the density)
+        n = n or (1 << 26)
+        radius = float(np.sqrt(n / (np.pi * 4e-3)))
+        side = 2.0 * radius * 1.0263
+        b = (side, side)
+        st = disk_state(n, b, radius, rng)
+        st['temperatures'] = rng.uniform(0.5, 0.9, (n, 1))
+        return "C4 %d-particle dense hot disk R=%.0f (4x default density), all stages" % (n, radius), n, b, st, 31
     raise SystemExit("unknown workload " + name)
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The oracle (C restatement of the reference's single-core CPU path) timed
-    on this host on a bounded sample of the C2 workload: 262,144 particles at
-    the same density (bounds 22500x11250), all stages."""
+def cpu_baseline(n, bounds, state, primed_accelerations, mask, label):
+    """The oracle (C restatement of the reference's single-core CPU path) timed on this
+    host on the benchmark's own initial state, full size: ONE update() after priming.
+    The priming accelerations a(0) are handed over from the device run (priming is outside
+    the timed region on both sides, and computing it again on one core would only add a
+    minute of untimed work).  The build used is the one whose six `fastmath` stages of the
+    reference (tree walk, potential energy, the two sweeps' sums, conduction) are compiled
+    with -ffast-math as Numba would; the strict stages stay strict."""
     from oracle import oracle as orc
-    n, bounds = 1 << 18, (22500, 11250)
-    o = orc.OracleSystem(n, SIM, np.random.default_rng(42), bounds)
+    o = orc.OracleSystem(n, SIM, np.random.default_rng(42), bounds, state=state, stage_mask=mask, fast_stages=True)
     o.set_fast_pow(True)      # x**-1.5 as 1/(x sqrt x), what an optimising JIT emits
-    o._calculate_gravity()
+    o.accelerations[:] = primed_accelerations
     t0 = time.perf_counter()
-    steps = 0
-    updates = 0
-    while steps < 2 or (time.perf_counter() - t0 < seconds_budget and steps < 50):
-        o.update()
-        steps += 1
-        updates += o.num_particles
+    o.update()
     dt = time.perf_counter() - t0
-    return {"value": updates / dt, "unit": "particle-updates/s", "cores": 1, "kind": "port",
-            "sample": "%d steps of a %d-particle cut of the workload at the same density (bounds %dx%d), "
-                      "oracle/psim_oracle.c, gcc -O2, one thread" % (steps, n, bounds[0], bounds[1])}
+    return {"value": o.num_particles / dt, "unit": "particle-updates/s", "cores": 1, "kind": "port",
+            "seconds": dt,
+            "sample": "1 full step of the workload itself (%s; %d particles) after priming, oracle/psim_oracle.c, "
+                      "gcc -O2 with -ffast-math on the reference's fastmath stages, one thread" % (label, n)}
+
+
+def launch_ranks(n_ranks):
+    """Start one fresh process per rank (this process has not touched the GPU or imported
+    torch) and hand rank 0's output through.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            code = p.wait()
+            rc = rc or code
+            if code != 0:
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    return rc
 
 
 def main():
@@ -103,14 +145,23 @@ def main():
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--walk-mode", type=int, default=0)
-    ap.add_argument("--library", default=None, help="alternative build of libpsim_hip.so (kernel experiments)")
+    ap.add_argument("--library", default=None,
+                    help="alternative build of the library (kernel experiments; the test-only host-loop build, "
+                         "with --backend gloo, for the CPU test of the multi-rank path)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--staged", action="store_true",
                     help="drive the step through the psim_stage_* entry points (the multi-GPU path) even on one GPU")
     ap.add_argument("--no-overlap", action="store_true",
                     help="every stage on one stream (kernel timings without the side stream's contention)")
-    ap.add_argument("--brute", type=int, default=0,
-                    help="also time the all-pairs cross-check kernel on this many particles")
+    ap.add_argument("--brute", type=int, default=262144,
+                    help="also time the all-pairs cross-check kernel on this many particles (0 = skip)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+
+    # --gpus N without a launcher: this process only starts the N ranks and waits for them
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     # stdout carries exactly one JSON line: libraries that print there (RCCL announces its
     # version on stdout when a communicator is created) are sent to stderr instead
@@ -123,9 +174,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    on_gpu = args.library is None or args.backend == "nccl"
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
     if world > 1 or args.staged:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -134,7 +187,10 @@ def main():
                 with socket.socket() as sk:
                     sk.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from psim_amd.particle_system import ParticleSystem
     # N = 1: C2 (4Mi, the single-GPU configuration the metric is quoted on).
@@ -146,20 +202,28 @@ def main():
     if world > 1 or args.staged:
         from psim_amd.distributed import ShardedParticleSystem
         ps = ShardedParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds, device=local_rank,
-                                   stage_mask=mask, walk_mode=args.walk_mode, state=state)
+                                   stage_mask=mask, walk_mode=args.walk_mode, state=state, library=args.library)
     else:
         ps = ParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds, device=local_rank,
                             stage_mask=mask, walk_mode=args.walk_mode, state=state, library=args.library,
                             overlap=not args.no_overlap)
+    want_cpu = not args.no_cpu_baseline and world == 1 and rank == 0
+    initial = None
+    if want_cpu:
+        initial = dict(positions=ps.positions.copy(), masses=ps.masses.copy(), temperatures=ps.temperatures.copy(),
+                       velocities=ps.velocities.copy())
     ps._calculate_gravity()
+    primed = ps.accelerations.copy() if want_cpu else None
     for _ in range(args.warmup):
         ps.update()
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     stage_acc = {}
     barrier()
@@ -172,15 +236,19 @@ def main():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
+    steps = max(args.steps, 1)
+    stage_ms = {k: v / steps for k, v in stage_acc.items()}
+    walk_ms_ranks = [stage_ms.get("gravity", 0.0)]
     if world > 1:
         # one simulation: every rank counted the same updates; time = slowest rank
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax[0])
+        every = [None] * world
+        dist.all_gather_object(every, stage_ms.get("gravity", 0.0))
+        walk_ms_ranks = [float(v) for v in every]
 
     if rank == 0:
-        steps = max(args.steps, 1)
-        stage_ms = {k: v / steps for k, v in stage_acc.items()}
         # dominant kernel: the Barnes-Hut walk (one launch per step).  Algorithmic
         # flops per launch = 20 I + 8 (V - I), I = accepted interactions, V = node
         # visits summed over particles, both counted on the current tree.
@@ -190,13 +258,13 @@ def main():
             # a rank's launch walks 1/world of the (Morton-sorted) targets: per-GPU figure,
             # taking the ranks' shares of the work as equal
             flops /= world
-        walk_ms = stage_ms.get("gravity", 0.0)
+        walk_ms = max(walk_ms_ranks)
         achieved = flops / (walk_ms * 1e-3) / 1e12 if walk_ms > 0 else 0.0
         counts = ps.counts()
         # In the step the walk shares the device: it holds part of the wave slots and the
         # grid build and contact solver run in the rest.  The same kernel on the same tree
         # with the device to itself, for comparison:
-        alone_ms = ps.time_walk(3, 0.0) if world == 1 else None
+        alone_ms = ps.time_walk(3, 0.0) if (world == 1 and on_gpu) else None
         out = {
             "metric": "particle-updates/sec", "value": updates / dt, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -213,24 +281,24 @@ def main():
                          "visits_per_particle": visits / max(ps.num_particles, 1),
                          "wave_trips_per_wave": ps.last_walk_trips[0] / max((ps.num_particles + 63) // 64, 1),
                          "force_trips_per_wave": ps.last_walk_trips[1] / max((ps.num_particles + 63) // 64, 1),
-                         "note": "kernel_ms is the walk's duration inside the timed steps, where other stages run "
-                                 "concurrently in wave slots the walk leaves free; device_to_itself is the same "
-                                 "launch with nothing else running"},
+                         "note": "kernel_ms is the walk's duration inside the timed steps (HIP events on the stream it is "
+                                 "launched on), where other stages run concurrently in wave slots the walk leaves free; "
+                                 "device_to_itself is the same launch with nothing else running.  traffic: the walk is "
+                                 "issue-bound, its HBM counters are kept under profiles/ and not repeated here"},
             "stage_ms": stage_ms,
             "last_step": {"contacts": counts["contacts"], "solver_iterations": counts["solver_iterations"],
                           "solver_rounds": counts["solver_rounds"], "tree_nodes": counts["tree_nodes"],
                           "particles": counts["particles"]},
         }
-        if wl == "c2" and world == 1:
-            # recorded, not measured by this run: counters need rocprofv3 passes of their own
-            out["roofline"]["traffic_recorded"] = {
-                "fetch_bytes": 2.69e9, "write_bytes": 1.35e8, "algorithmic_bytes": 4.4e8,
-                "source": "profiles/r1_walk_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                          "raw counters; 32-byte scalar fetches are not a calibrated pattern on gfx950)"}
+        if world > 1:
+            out["roofline"]["kernel_ms_per_rank"] = walk_ms_ranks
+            out["roofline"]["frac_per_rank"] = [flops / (m * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if m > 0 else 0.0
+                                                for m in walk_ms_ranks]
         if alone_ms:
             tf = flops / (alone_ms * 1e-3) / 1e12
             out["roofline"]["device_to_itself"] = {"kernel_ms": alone_ms, "achieved": tf, "frac": tf / PEAK_FP64_VALU_TFLOPS}
-        if args.brute:
+        if args.brute and on_gpu and world == 1:
+            # yardstick: the same force arithmetic with no tree and no divergence
             nb = args.brute
             side = float(np.sqrt(nb / 1e-3))
             bs = ParticleSystem(nb, dict(SIM), np.random.default_rng(7), (side, side), device=local_rank)
@@ -241,8 +309,9 @@ def main():
                                   "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                                   "frac": tf / PEAK_FP64_VALU_TFLOPS}
             bs.close()
-        if not args.no_cpu_baseline and world == 1:      # (one rank only: the other ranks would wait at the barrier)
-            out["cpu_baseline"] = cpu_baseline()
+        if want_cpu:      # (one rank only: the other ranks would wait at the barrier)
+            ps.close()
+            out["cpu_baseline"] = cpu_baseline(n, bounds, initial, primed, mask, label)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.staged:

@@ -57,7 +57,9 @@ typedef struct psim_config {
     int32_t solver_iterations;        /* config.json:21 collision_solver_iterations (default 1) */
     int32_t stage_mask;               /* PSIM_STAGE_*; the reference has no such switch */
     int32_t walk_mode;                /* 0 = wave-cooperative tree walk, two particle groups per wave;
-                                         1 = one lane per particle; 2 = wave-cooperative, one group per wave */
+                                         1 = one lane per particle; 2 = wave-cooperative, one group per wave;
+                                         3 / 4 = as 0 / 2 with the 64-bit element offsets the kernels switch to
+                                         for trees of 4 GiB and more forced on (tests) */
     int32_t debug;                    /* 1 = keep the per-step contact log and delta-temperature array */
     int32_t overlap;                  /* 1 = run the grid build and the first contact-sweep count pass on a
                                          side stream underneath the tree walk (default in the Python binding) */

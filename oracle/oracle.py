@@ -16,6 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libpsim_oracle.so")
+_SO_FAST = os.path.join(_HERE, "libpsim_oracle_fast.so")
 _SRC = os.path.join(_HERE, "psim_oracle.c")
 
 COLOR_MAX_TEMP = 1.0   # constants.py:33
@@ -24,25 +25,29 @@ STAGE_ALL = 31
 STAGE_GRAVITY_ONLY = 0
 
 
-def build(force=False):
-    """Compile the oracle with gcc (strict FP64, no contraction)."""
-    if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= os.path.getmtime(_SRC)):
-        return _SO
-    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
-                           "-shared", "-fPIC", "-o", _SO, _SRC, "-lm"])
-    return _SO
+def build(force=False, fast_stages=False):
+    """Compile the oracle with gcc (strict FP64, no contraction).  fast_stages: the second
+    build, used for CPU timing only, in which the functions restating the reference's six
+    `fastmath=True` kernels carry -ffast-math (the strict ones stay strict)."""
+    so = _SO_FAST if fast_stages else _SO
+    if (not force and os.path.exists(so)
+            and os.path.getmtime(so) >= os.path.getmtime(_SRC)):
+        return so
+    extra = ["-DORC_FAST_STAGES"] if fast_stages else []
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp"] + extra +
+                          ["-shared", "-fPIC", "-o", so, _SRC, "-lm"])
+    return so
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_SO):
-            build()
-        L = ctypes.CDLL(_SO)
+def lib(fast_stages=False):
+    if fast_stages not in _libs:
+        so = _SO_FAST if fast_stages else _SO
+        if not os.path.exists(so):
+            build(fast_stages=fast_stages)
+        L = ctypes.CDLL(so)
         L.orc_create.restype = ctypes.c_void_p
         L.orc_create.argtypes = [ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.c_int,
                                  ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -67,8 +72,8 @@ def lib():
         L.orc_enable_contact_log.argtypes = [ctypes.c_void_p, ctypes.c_int64]
         L.orc_set_fast_pow.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        _lib = L
-    return _lib
+        _libs[fast_stages] = L
+    return _libs[fast_stages]
 
 
 def grid_geometry(config, bounds):
@@ -105,9 +110,11 @@ def _view(addr, shape, dtype):
 
 
 class OracleSystem:
-    def __init__(self, num_particles, config, rng, bounds, *, state=None, stage_mask=STAGE_ALL):
+    def __init__(self, num_particles, config, rng, bounds, *, state=None, stage_mask=STAGE_ALL, fast_stages=False):
         """state: optional dict(positions, velocities, masses, temperatures[, accelerations])
-        used instead of the RNG draws (synthetic benchmark clouds)."""
+        used instead of the RNG draws (synthetic benchmark clouds).  fast_stages: bind the
+        timing build (see build())."""
+        self._L = lib(fast_stages)
         self.num_particles = int(num_particles)
         self.config = config
         self.bounds = np.array(bounds)
@@ -126,7 +133,7 @@ class OracleSystem:
             velocities = np.asarray(state.get('velocities', np.zeros((n, 2))), dtype=np.float64).reshape(n, 2)
             accelerations = np.asarray(state.get('accelerations', np.zeros((n, 2))), dtype=np.float64).reshape(n, 2)
         self.cell_size, self.grid_width, self.grid_height = grid_geometry(config, bounds)
-        L = lib()
+        L = self._L
         cfg = config_vector(config, bounds)
         self._h = L.orc_create(n, cfg.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                int(config.get('collision_solver_iterations', 1)),
@@ -147,10 +154,10 @@ class OracleSystem:
             raise RuntimeError("oracle: node pool overflow (coincident particles)")
 
     def _p(self, which):
-        return lib().orc_ptr(self._h, which)
+        return self._L.orc_ptr(self._h, which)
 
     def _bind(self):
-        n = int(lib().orc_get_i(self._h, 0))
+        n = int(self._L.orc_get_i(self._h, 0))
         self.num_particles = n
         self.positions = _view(self._p(0), (n, 2), np.float64)
         self.velocities = _view(self._p(1), (n, 2), np.float64)
@@ -163,7 +170,7 @@ class OracleSystem:
     def __del__(self):
         try:
             if self._h:
-                lib().orc_destroy(self._h)
+                self._L.orc_destroy(self._h)
                 self._h = None
         except Exception:
             pass
@@ -172,17 +179,17 @@ class OracleSystem:
     def _calculate_gravity(self):
         v = ctypes.c_int64(0)
         i = ctypes.c_int64(0)
-        lib().orc_gravity(self._h, ctypes.byref(v), ctypes.byref(i))
+        self._L.orc_gravity(self._h, ctypes.byref(v), ctypes.byref(i))
         self.last_visits, self.last_interactions = v.value, i.value
 
     def update(self):
-        rc = lib().orc_update(self._h, self.stage_mask)
+        rc = self._L.orc_update(self._h, self.stage_mask)
         if rc != 0:
             raise RuntimeError("oracle: node pool overflow (coincident particles)")
         t = (ctypes.c_double * 3)()
-        lib().orc_get_collision_totals(self._h, t)
+        self._L.orc_get_collision_totals(self._h, t)
         self.pe_gain_collisions, self.ke_loss_collisions, self.heat_generated_collisions = t[0], t[1], t[2]
-        if int(lib().orc_get_i(self._h, 0)) != self.num_particles:
+        if int(self._L.orc_get_i(self._h, 0)) != self.num_particles:
             self._bind()
 
     def get_total_kinetic_energy(self):
@@ -193,24 +200,24 @@ class OracleSystem:
         return np.sum(self.masses * self.temperatures)                     # :783
 
     def get_total_potential_energy(self):
-        return lib().orc_potential_energy(self._h)
+        return self._L.orc_potential_energy(self._h)
 
     # -- stage access for tests -------------------------------------------
     def enable_contact_log(self, cap):
-        lib().orc_enable_contact_log(self._h, cap)
+        self._L.orc_enable_contact_log(self._h, cap)
 
     def set_fast_pow(self, on):
-        lib().orc_set_fast_pow(self._h, 1 if on else 0)
+        self._L.orc_set_fast_pow(self._h, 1 if on else 0)
 
     def set_threads(self, k):
         """threads of the per-particle gravity loop (results do not depend on it)"""
-        lib().orc_set_threads(self._h, int(k))
+        self._L.orc_set_threads(self._h, int(k))
 
     def build_grid(self):
-        lib().orc_build_grid(self._h)
+        self._L.orc_build_grid(self._h)
 
     def build_tree(self):
-        return lib().orc_build_tree(self._h)
+        return self._L.orc_build_tree(self._h)
 
     @property
     def grid_offsets(self):
@@ -218,31 +225,31 @@ class OracleSystem:
 
     @property
     def grid_indices(self):
-        return _view(self._p(8), (int(lib().orc_get_i(self._h, 6)),), np.int32)
+        return _view(self._p(8), (int(self._L.orc_get_i(self._h, 6)),), np.int32)
 
     @property
     def num_active_nodes(self):
-        return int(lib().orc_get_i(self._h, 1))
+        return int(self._L.orc_get_i(self._h, 1))
 
     @property
     def n_candidates(self):
-        return int(lib().orc_get_i(self._h, 2))
+        return int(self._L.orc_get_i(self._h, 2))
 
     @property
     def n_contacts(self):
-        return int(lib().orc_get_i(self._h, 3))
+        return int(self._L.orc_get_i(self._h, 3))
 
     @property
     def exploded(self):
-        k = int(lib().orc_get_i(self._h, 4))
+        k = int(self._L.orc_get_i(self._h, 4))
         return _view(self._p(17), (k,), np.int32).copy()
 
     @property
     def delta_temps(self):
-        return _view(self._p(16), (int(lib().orc_get_i(self._h, 6)),), np.float64)
+        return _view(self._p(16), (int(self._L.orc_get_i(self._h, 6)),), np.float64)
 
     def contact_log(self):
-        k = int(lib().orc_get_i(self._h, 5))
+        k = int(self._L.orc_get_i(self._h, 5))
         return (_view(self._p(18), (k, 2), np.int32).copy(),
                 _view(self._p(19), (k, 3), np.float64).copy())
 

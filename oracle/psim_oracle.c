@@ -31,6 +31,17 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Timing build only (-DORC_FAST_STAGES, libpsim_oracle_fast.so): the functions that restate
+ * the reference's six `@numba.jit(fastmath=True)` kernels (particle_system.py:17, 27, 69,
+ * 137, 271, 312) are compiled with -ffast-math, as Numba compiles them; everything else,
+ * in particular the strict pair resolver (:200) and the tree build, stays strict.  The
+ * parity tests never use this build. */
+#if defined(ORC_FAST_STAGES)
+#define ORC_FAST __attribute__((optimize("fast-math")))
+#else
+#define ORC_FAST
+#endif
+
 typedef struct {
     /* configuration (reference: config.json "simulation", particle_system.py:355-397) */
     double min_mass, max_mass;
@@ -241,14 +252,14 @@ static int build_tree(orc_system *s)
 }
 
 /* ---------------------------------------------------------------- gravity */
-static inline double inv_cubed(const orc_system *s, double x)
+static inline ORC_FAST double inv_cubed(const orc_system *s, double x)
 {
     if (s->fast_pow) { double r = 1.0 / sqrt(x); return r * r * r; }
     return pow(x, -1.5);            /* particle_system.py:90,117 */
 }
 
 /* particle_system.py:69-121 _traverse_tree_jit */
-static void traverse(const orc_system *s, int64_t p, int64_t node, double *fx, double *fy,
+static ORC_FAST void traverse(const orc_system *s, int64_t p, int64_t node, double *fx, double *fy,
                      int64_t *visits, int64_t *inter)
 {
     const double *nd = &s->node_data[4 * node];
@@ -291,7 +302,7 @@ static void traverse(const orc_system *s, int64_t p, int64_t node, double *fx, d
 }
 
 /* particle_system.py:409-437 _calculate_gravity + :17-25 */
-static void gravity(orc_system *s, int64_t *visits, int64_t *inter)
+static ORC_FAST void gravity(orc_system *s, int64_t *visits, int64_t *inter)
 {
     int64_t v = 0, it = 0;
     memset(s->acc, 0, sizeof(double) * 2 * s->n);
@@ -310,7 +321,7 @@ static void gravity(orc_system *s, int64_t *visits, int64_t *inter)
 }
 
 /* particle_system.py:27-67 _calculate_potential_energy_jit */
-static double potential(const orc_system *s, int64_t node)
+static ORC_FAST double potential(const orc_system *s, int64_t node)
 {
     double total = 0.0;
     if (s->node_children[4 * node] == -1) return 0.0;
@@ -397,7 +408,7 @@ static void candidate(orc_system *s, int32_t a, int32_t b, double *tpe, double *
 }
 
 /* particle_system.py:137-198 _handle_collisions_jit: one Gauss-Seidel sweep */
-static void collision_sweep(orc_system *s, double *tpe, double *tke, double *th)
+static ORC_FAST void collision_sweep(orc_system *s, double *tpe, double *tke, double *th)
 {
     int gw = s->grid_w, gh = s->grid_h;
     const int32_t *off = s->grid_offsets, *idx = s->grid_indices;
@@ -441,7 +452,7 @@ static void collisions(orc_system *s)
 
 /* ---------------------------------------------------------------- conduction */
 /* particle_system.py:312-336 _transfer_heat_between_pair_jit */
-static inline void heat_pair(orc_system *s, int32_t a, int32_t b, double *delta)
+static inline ORC_FAST void heat_pair(orc_system *s, int32_t a, int32_t b, double *delta)
 {
     double dx = s->pos[2 * b] - s->pos[2 * a], dy = s->pos[2 * b + 1] - s->pos[2 * a + 1];
     double d2 = dx * dx + dy * dy;
@@ -457,7 +468,7 @@ static inline void heat_pair(orc_system *s, int32_t a, int32_t b, double *delta)
 }
 
 /* particle_system.py:476-498 + :271-310 */
-static void conduction(orc_system *s)
+static ORC_FAST void conduction(orc_system *s)
 {
     int gw = s->grid_w, gh = s->grid_h;
     const int32_t *off = s->grid_offsets, *idx = s->grid_indices;

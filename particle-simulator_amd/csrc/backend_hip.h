@@ -1067,7 +1067,7 @@ template <int K>
 inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
                               const vec2* spos, const double* smass, const uint32_t* perm, const double* inv_mass,
                               vec2* out, bool fold, uint32_t w2_lo, double theta2, double g_const, double softening,
-                              uint32_t* chunk_counter, int64_t resident_waves)
+                              uint32_t* chunk_counter, int64_t resident_waves, bool force_wide = false)
 {
     if (hi <= lo) return;
     int64_t chunks = (hi - lo + 64 * K - 1) / (64 * K);
@@ -1076,7 +1076,8 @@ inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out,
     int64_t blocks = chunks;
     if (chunk_counter && resident_waves > 0 && resident_waves < chunks) blocks = resident_waves;
     else chunk_counter = nullptr;
-    const bool wide = (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
+    // (force_wide: the 64-bit-offset variant on a small array, for tests)
+    const bool wide = force_wide || (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
                            perm, inv_mass, out, w2_lo, theta2, g_const, softening, (uint32_t)chunks, chunk_counter);
@@ -1092,12 +1093,12 @@ template <bool COUNT>
 inline void launch_walk(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
                         const vec2* spos, const double* smass, const uint32_t* perm, const double* inv_mass, vec2* out,
                         bool fold, uint32_t w2_lo, double theta2, double g_const, double softening,
-                        unsigned long long* counters)
+                        unsigned long long* counters, bool force_wide = false)
 {
     if (hi <= lo) return;
     int64_t blocks = (hi - lo + 255) / 256;
     if (blocks > 0x7fffffffLL) throw std::runtime_error("launch_walk: grid too large");
-    const bool wide = (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
+    const bool wide = force_wide || (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
                            perm, inv_mass, out, w2_lo, theta2, g_const, softening, counters);

@@ -25,20 +25,21 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     uint32_t total = (uint32_t)(n + n_internal);
     double theta2 = cfg.theta * cfg.theta;          // particle_system.py:88 theta * theta * dist_sq
 #if !defined(PSIM_HOSTLOOP)
-    if (cfg.walk_mode == 0) {
-        // default: two walks per wave
+    if (cfg.walk_mode == 0 || cfg.walk_mode == 3) {
+        // default: two walks per wave (3: with 64-bit element offsets forced, as on arrays of 4 GiB and more)
         be::launch_walk_multi<2>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
                                  (const double*)smass.p, (const uint32_t*)perm[sorted_key].p,
                                  (const double*)inv_mass.p, out, walk_fold, (uint32_t)w2_cmp_bits, theta2,
-                                 cfg.gravity_constant, cfg.softening, walk_ctr.p, walk_resident_waves());
+                                 cfg.gravity_constant, cfg.softening, walk_ctr.p, walk_resident_waves(),
+                                 cfg.walk_mode == 3);
         return;
     }
-    if (cfg.walk_mode == 2) {
+    if (cfg.walk_mode == 2 || cfg.walk_mode == 4) {
         // one walk per wave (the kernel the visit / interaction counts are taken with)
         be::launch_walk<false>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
                                (const double*)smass.p, (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p,
                                out, walk_fold, (uint32_t)w2_cmp_bits, theta2, cfg.gravity_constant, cfg.softening,
-                               (unsigned long long*)nullptr);
+                               (unsigned long long*)nullptr, cfg.walk_mode == 4);
         return;
     }
 #endif
@@ -300,16 +301,19 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     use_device(ctx->device);
     psim::Sim* s = ctx->sim;
     out[0] = out[1] = out[2] = out[3] = 0;
-    if (!s->tree_valid || s->n == 0) throw std::runtime_error("psim: no tree built yet");
-    uint32_t total = (uint32_t)(s->n + s->n_internal);
+    if (!s->tree_valid || s->walk_n == 0) throw std::runtime_error("psim: no tree built yet");
+    // the tree describes the particles it was built from: after a step that removed particles
+    // by explosion that is more than the current count (the removed ones are still in it)
+    const int64_t tn = s->walk_n;
+    uint32_t total = (uint32_t)(tn + s->n_internal);
     double theta2 = s->cfg.theta * s->cfg.theta;
     psim::DevBuf<psim::vec2> scratch;
-    scratch.ensure((size_t)s->n);
+    scratch.ensure((size_t)tn);
 #if !defined(PSIM_HOSTLOOP)
     psim::DevBuf<unsigned long long> cnt;
     cnt.ensure(32);
     psim::be::dev_memset(s->st, cnt.p, 0, 256);
-    psim::be::launch_walk<true>(s->st, (int64_t)0, s->n, 0, (const psim::NodeRec*)s->rec.p, total,
+    psim::be::launch_walk<true>(s->st, (int64_t)0, tn, 0, (const psim::NodeRec*)s->rec.p, total,
                                 (const psim::vec2*)s->spos.p, (const double*)s->smass.p,
                                 (const uint32_t*)s->perm[s->sorted_key].p, (const double*)s->inv_mass.p, scratch.p,
                                 s->walk_fold, (uint32_t)s->w2_cmp_bits, theta2, s->cfg.gravity_constant,
@@ -326,10 +330,10 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     cnt.ensure(2);
     psim::be::dev_memset(s->st, cnt.p, 0, 8);
     psim::GravityWalkSimple k;
-    k.n = s->n; k.s0 = 0; k.sorted_out = 0; k.rec = s->rec.p; k.total_elems = total; k.spos = s->spos.p; k.smass = s->smass.p;
+    k.n = tn; k.s0 = 0; k.sorted_out = 0; k.rec = s->rec.p; k.total_elems = total; k.spos = s->spos.p; k.smass = s->smass.p;
     k.perm = s->perm[s->sorted_key].p; k.inv_mass = s->inv_mass.p; k.acc_out = scratch.p; k.w2tab = s->w2tab.p;
     k.root_tag = s->root_tag(); k.theta2 = theta2; k.g_const = s->cfg.gravity_constant; k.softening = s->cfg.softening; k.counters = cnt.p;
-    psim::be::launch(s->st, s->n, k);
+    psim::be::launch(s->st, tn, k);
     out[0] = cnt.p[0];
     out[1] = cnt.p[1];
     out[2] = out[3] = 0;
@@ -346,17 +350,18 @@ static void time_walk_impl(psim_context* ctx, int32_t reps, double slots_per_sim
     use_device(ctx->device);
     psim::Sim* s = ctx->sim;
     *ms_avg = 0.0;
-    if (!s->tree_valid || s->n == 0) throw std::runtime_error("psim: no tree built yet");
+    if (!s->tree_valid || s->walk_n == 0) throw std::runtime_error("psim: no tree built yet");
     if (reps < 1 || reps > 1000 || !(slots_per_simd >= 0.0) || slots_per_simd > 8.0)
         throw std::invalid_argument("psim: bad repetition count or slot count");
 #if !defined(PSIM_HOSTLOOP)
-    uint32_t total = (uint32_t)(s->n + s->n_internal);
+    const int64_t tn = s->walk_n;       // (see walk_counts_impl)
+    uint32_t total = (uint32_t)(tn + s->n_internal);
     double theta2 = s->cfg.theta * s->cfg.theta;
     psim::DevBuf<psim::vec2> scratch;
-    scratch.ensure((size_t)s->n);
+    scratch.ensure((size_t)tn);
     int64_t resident = (int64_t)(psim::be::compute_units() * 4 * slots_per_simd);
     auto once = [&]() {
-        psim::be::launch_walk_multi<2>(s->st, (int64_t)0, s->n, 0, (const psim::NodeRec*)s->rec.p, total,
+        psim::be::launch_walk_multi<2>(s->st, (int64_t)0, tn, 0, (const psim::NodeRec*)s->rec.p, total,
                                        (const psim::vec2*)s->spos.p, (const double*)s->smass.p,
                                        (const uint32_t*)s->perm[s->sorted_key].p, (const double*)s->inv_mass.p, scratch.p,
                                        s->walk_fold, (uint32_t)s->w2_cmp_bits, theta2, s->cfg.gravity_constant,

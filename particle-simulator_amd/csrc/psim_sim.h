@@ -73,7 +73,8 @@ public:
     be::Stream st;
     int64_t n = 0;
     bool tree_valid = false;
-    int64_t tree_n = 0;            // particle count the tree / grid were built for
+    int64_t tree_n = 0;            // particle count the grid was built for
+    int64_t walk_n = 0;            // particle count the tree (rec, perm, spos) was built for
     uint32_t n_internal = 0;
     int sorted_key = 0, sorted_ckey = 0;
     int slot_bits = 1;            // pair-key field width, from the largest cell population
@@ -171,20 +172,21 @@ public:
     // the walk).  Without collisions only the grid build is there: 7 slots from 8 Mi
     // particles on, the whole grid below.  Two free slots per SIMD are also what the exchange
     // kernels of a sharded step need (workgroups of up to 512 lanes).
-    // PSIM_WALK_WAVES=<per SIMD> and PSIM_POSITIONS_UNDER_WALK=<0|1> override (kernel experiments).
+    // (-DPSIM_WALK_SLOTS=<per SIMD> fixes the count at build time, for kernel experiments.)
     bool sharded_step = false;     // the step in progress is driven through the stage_* calls
     bool positions_under_walk() const
     {
-        static const char* e = getenv("PSIM_POSITIONS_UNDER_WALK");
-        if (e) return atoi(e) != 0;
         return cfg.overlap != 0;
     }
     int64_t walk_resident_waves() const
     {
-        static const char* e = getenv("PSIM_WALK_WAVES");
         double per_simd = 0;
-        if (e) per_simd = atof(e);
-        else if (cfg.overlap != 0 && n > 0) {
+#if defined(PSIM_WALK_SLOTS)
+        per_simd = PSIM_WALK_SLOTS;
+        if (false) {
+#else
+        if (cfg.overlap != 0 && n > 0) {
+#endif
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
             else per_simd = (n < (8ll << 20) && !sharded_step) ? 6.5 : 6;
         }
@@ -465,6 +467,7 @@ public:
         size_t c = (size_t)n;
         tree_valid = false;
         n_internal = 0;
+        walk_n = n;
         if (n == 0) { tree_valid = true; return; }
         sort_tmp.ensure(be::sort_temp_words(c));
         uint64_t* k[2] = {key[0].p, key[1].p};

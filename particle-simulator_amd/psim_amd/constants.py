@@ -19,15 +19,3 @@ COLOR_GRADIENT_KEYFRAMES = [
 TRAIL_EFFECT_COLOR = (0, 0, 0, 30)
 BLOOM_RADIUS = 20
 BLOOM_INTENSITY = 30
-
-
-def ramp_colors(t):
-    """Vectorised colour ramp (particle_system.py:565-585): linear blend between
-    the two keyframes around each t in [0, 1], channels truncated to int."""
-    t = np.asarray(t, dtype=np.float64)
-    pos = np.array([k[0] for k in COLOR_GRADIENT_KEYFRAMES])
-    col = np.array([k[1] for k in COLOR_GRADIENT_KEYFRAMES], dtype=np.float64)
-    seg = np.clip(np.searchsorted(pos, t, side="left") - 1, 0, len(pos) - 2)
-    local = (t - pos[seg]) / (pos[seg + 1] - pos[seg])
-    rgb = col[seg] * (1 - local)[:, None] + col[seg + 1] * local[:, None]
-    return rgb.astype(np.int64)

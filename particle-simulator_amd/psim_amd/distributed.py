@@ -61,6 +61,7 @@ class ShardedParticleSystem(ParticleSystem):
         self._acc = torch.zeros((per * self._world, 2), dtype=torch.float64, device=self._tdev)
         self._tmp = torch.zeros((per * self._world,), dtype=torch.float64, device=self._tdev)
         self._keys = torch.zeros((max(4096, per // 8),), dtype=torch.int64, device=self._tdev)
+        self._cat_keys = None
         self._all_keys = None
         # the small exchanges of the contact lists run on a stream of their own, so that they
         # are not ordered behind the walk (which is on the default stream)
@@ -69,40 +70,48 @@ class ShardedParticleSystem(ParticleSystem):
     def _detect_and_gather(self, lo, hi):
         """contact detection of the first collision sweep on this rank's slab of grid slots,
         then the ranks' key lists gathered -> (tensor of all keys, contacts, candidates,
-        coincident pairs)"""
+        coincident pairs).
+
+        One collective: every rank sends a block of `cap` words -- three counters (contacts,
+        candidates, coincident pairs), then its keys -- and reads the counters of all blocks
+        back once.  A rank whose list did not fit makes everybody grow the block and repeat
+        (the counters tell all ranks the same thing)."""
         L, ctx = self._lib, self._ctx
         out = (ctypes.c_int64 * 4)()
-        while True:
-            _capi.check(L, L.psim_stage_detect(ctx, lo, hi, ctypes.c_void_p(self._keys.data_ptr()),
-                                               self._keys.numel(), out))
-            if out[3] == out[0]:
-                break
-            self._keys = torch.zeros((int(out[0]) + int(out[0]) // 4 + 4096,), dtype=torch.int64, device=self._tdev)
-        mine = [int(out[0]), int(out[1]), int(out[2])]
-        if self._world == 1:
-            return self._keys, mine[0], mine[1], mine[2]
         import contextlib
         side = torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
-        with side:
-            counts = torch.tensor(mine, dtype=torch.int64, device=self._tdev)
-            every = torch.zeros((self._world * 3,), dtype=torch.int64, device=self._tdev)
-            dist.all_gather_into_tensor(every, counts, group=self._group)
-            every = every.cpu().view(self._world, 3)
-            n_each = [int(v) for v in every[:, 0]]
-            most = max(n_each)
-            total = sum(n_each)
-            if most == 0:
-                return self._keys, 0, int(every[:, 1].sum()), int(every[:, 2].sum())
-            if self._keys.numel() < most:        # the padded send buffer must hold the longest list
-                grown = torch.zeros((most + most // 4 + 4096,), dtype=torch.int64, device=self._tdev)
-                grown[: mine[0]] = self._keys[: mine[0]]
-                self._keys = grown
-            padded = torch.empty((self._world * most,), dtype=torch.int64, device=self._tdev)
-            dist.all_gather_into_tensor(padded, self._keys[:most], group=self._group)
-            self._all_keys = torch.cat([padded[r * most: r * most + n_each[r]] for r in range(self._world)])
-            if self._side is not None:
-                self._side.synchronize()
-        return self._all_keys, total, int(every[:, 1].sum()), int(every[:, 2].sum())
+        while True:
+            cap = self._keys.numel() - 3
+            _capi.check(L, L.psim_stage_detect(ctx, lo, hi, ctypes.c_void_p(self._keys.data_ptr() + 24), cap, out))
+            mine = [int(out[0]), int(out[1]), int(out[2])]
+            if self._world == 1:
+                if out[3] == out[0]:
+                    return self._keys[3:], mine[0], mine[1], mine[2]
+                # (no fill: the library writes the keys on a stream of its own, and a fill queued
+                # on this one behind the walk would land on top of them later)
+                self._keys = torch.empty((mine[0] + mine[0] // 4 + 4096,), dtype=torch.int64, device=self._tdev)
+                continue
+            with side:
+                self._keys[:3] = torch.tensor(mine, dtype=torch.int64).to(self._tdev, non_blocking=False)
+                block = self._keys.numel()
+                if self._all_keys is None or self._all_keys.numel() != self._world * block:
+                    self._all_keys = torch.empty((self._world * block,), dtype=torch.int64, device=self._tdev)
+                dist.all_gather_into_tensor(self._all_keys, self._keys, group=self._group)
+                blocks = self._all_keys.view(self._world, block)
+                every = blocks[:, :3].cpu()
+                n_each = [int(v) for v in every[:, 0]]
+                most = max(n_each)
+                if most > cap:
+                    self._keys = torch.empty((most + most // 4 + 4096,), dtype=torch.int64, device=self._tdev)
+                    continue
+                total = sum(n_each)
+                keys = self._keys
+                if total > 0:
+                    keys = torch.cat([blocks[r, 3: 3 + n_each[r]] for r in range(self._world)])
+                    if self._side is not None:
+                        self._side.synchronize()
+                self._cat_keys = keys      # (kept alive while the library copies from it)
+            return keys, total, int(every[:, 1].sum()), int(every[:, 2].sum())
 
     def _gather(self, buf, per, async_op=False):
         """in-place all-gather of the ranks' equal shards of buf[: per * world];
@@ -117,6 +126,7 @@ class ShardedParticleSystem(ParticleSystem):
         L, ctx = self._lib, self._ctx
         for _ in range(int(steps)):
             self._sync_config()
+            self._sync_state()
             _capi.check(L, L.psim_stage_build(ctx))
             n = int(L.psim_num_particles(ctx))
             lo, hi, per = shard_range(n, self._rank, self._world)
@@ -135,18 +145,16 @@ class ShardedParticleSystem(ParticleSystem):
                                                                   cand, coinc))
             else:
                 _capi.check(L, L.psim_stage_settle_positions(ctx))
+            # (the library's main stream is the device's default stream, which is also the
+            # stream work.wait() makes wait for the collective: no host synchronisation)
             if work is not None:
                 work.wait()
-            if self._tdev.type == "cuda":
-                torch.cuda.current_stream().synchronize()
             _capi.check(L, L.psim_stage_kick_collide(ctx, ctypes.c_void_p(self._acc.data_ptr())))
             _capi.check(L, L.psim_stage_conduction(ctx, lo, hi, ctypes.c_void_p(self._tmp.data_ptr())))
             exchanges = ctypes.c_int32(0)
             _capi.check(L, L.psim_stage_conduction_exchanges(ctx, ctypes.byref(exchanges)))
             if exchanges.value:      # same answer on every rank
                 self._gather(self._tmp, per)
-                if self._tdev.type == "cuda":
-                    torch.cuda.current_stream().synchronize()
             _capi.check(L, L.psim_stage_finish(ctx, ctypes.c_void_p(self._tmp.data_ptr())))
             self._stale = True
             t = (ctypes.c_double * 3)()

@@ -5,9 +5,17 @@ the C ABI of include/psim.h.  main.py of the reference runs unchanged on it:
     from psim_amd.particle_system import ParticleSystem
 
 State lives on the GPU.  The public arrays (`positions`, `velocities`,
-`accelerations`, `masses`, `inverse_masses`, `temperatures`, `radii`) are host
-NumPy arrays refreshed lazily: reading one after `update()` downloads the
-current state once.  Writes to them are pushed with `push_state()`.
+`accelerations`, `masses`, `inverse_masses`, `temperatures`, `radii`) are NumPy
+views over page-locked host tensors owned by PyTorch (`torch.empty(...,
+pin_memory=True)`; PyTorch is used for nothing else here), refreshed lazily:
+reading one after `update()` downloads the current state once, by DMA straight
+into the memory the view shows -- `draw()` reads them without a further copy.
+
+Writing: assigning an array (`ps.velocities = v`) takes effect at the next
+device call, as in the reference.  The views themselves are handed out
+read-only, so an in-place edit (`ps.velocities[0] = ...`) raises instead of
+being lost; `with ps.editing() as arrays:` gives writable views and uploads
+them on exit.
 """
 import ctypes
 import logging
@@ -106,10 +114,17 @@ class ParticleSystem:
         self._cfg_key = self._config_key()
         self._ctx = ctypes.c_void_p()
         _capi.check(self._lib, self._lib.psim_create(ctypes.byref(self._cfg), device, ctypes.byref(self._ctx)))
-        self._host = dict(positions=positions, velocities=velocities, accelerations=accelerations,
-                          masses=masses, inverse_masses=1.0 / masses, temperatures=temperatures,
-                          radii=radii.astype(np.int64))
+        self._pinned = library is None      # the test-only host-loop build has no device to pin for
+        self._store = {}
+        self._host = {}
+        self._feed = None
+        self._alloc_host(n)
+        for name, value in (("positions", positions), ("velocities", velocities), ("accelerations", accelerations),
+                            ("masses", masses), ("inverse_masses", 1.0 / masses), ("temperatures", temperatures),
+                            ("radii", radii.astype(np.int64))):
+            np.copyto(self._host[name], value)
         self._stale = False
+        self._dirty = False
         self._upload()
         logger.info(f"ParticleSystem created for {num_particles} particles.")
         logger.info(f"Spatial grid initialized with cell size {self.cell_size} "
@@ -132,34 +147,70 @@ class ParticleSystem:
             _capi.check(self._lib, self._lib.psim_set_config(self._ctx, ctypes.byref(self._cfg)))
             self._cfg_key = key
 
+    _SHAPES = dict(positions=(2, np.float64), velocities=(2, np.float64), accelerations=(2, np.float64),
+                   masses=(1, np.float64), inverse_masses=(1, np.float64), temperatures=(1, np.float64),
+                   radii=(1, np.int64))
+
+    def _host_block(self, rows, cols, dtype):
+        """(rows, cols) host array: a NumPy view of a page-locked PyTorch tensor (the tensor
+        owns the memory; the device copies into and out of it by DMA)."""
+        if not self._pinned:
+            return None, np.empty((rows, cols), dtype=dtype)
+        import torch
+        t = torch.empty((max(rows, 1), cols), dtype=getattr(torch, np.dtype(dtype).name), pin_memory=True)
+        return t, t.numpy()[:rows]
+
+    def _alloc_host(self, n):
+        """Backing store for n rows of every public array (allocated once: explosions only
+        shrink the count, and the public arrays are then views of the leading rows)."""
+        for name, (cols, dtype) in self._SHAPES.items():
+            self._store[name] = self._host_block(n, cols, dtype)
+        self._bind_host(n)
+
+    def _bind_host(self, n):
+        # the reference rebinds (does not resize) its arrays on explosion (:716-722)
+        for name in _FIELDS:
+            self._host[name] = self._store[name][1][:n]
+
     def _ptr(self, name):
         return self._host[name].ctypes.data_as(ctypes.c_void_p)
 
     def _upload(self):
-        h = self._host
-        for k in _FIELDS:
-            h[k] = np.ascontiguousarray(h[k])
         _capi.check(self._lib, self._lib.psim_upload(
             self._ctx, self.num_particles, self._ptr("positions"), self._ptr("velocities"),
             self._ptr("accelerations"), self._ptr("masses"), self._ptr("temperatures"), self._ptr("radii")))
         self._stale = False
+        self._dirty = False
 
     def push_state(self):
-        """Upload the host arrays after the caller modified them in place."""
+        """Upload the host arrays now (they are uploaded before the next device call anyway
+        once one of them was assigned or edited through editing())."""
         self._refresh()
         self._upload()
+
+    def _sync_state(self):
+        """host-side writes reach the device before it is used again"""
+        if self._dirty:
+            self._upload()
+
+    def editing(self):
+        """Context manager: writable views of the public arrays; uploaded on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            self._refresh()
+            yield dict(self._host)
+            self._dirty = True
+            self._sync_state()
+        return scope()
 
     def _refresh(self):
         if not self._stale:
             return
         n = int(self._lib.psim_num_particles(self._ctx))
-        h = self._host
-        if n != h["positions"].shape[0]:
-            # the reference rebinds (does not resize) its arrays on explosion (:716-722)
-            h["positions"] = np.empty((n, 2)); h["velocities"] = np.empty((n, 2))
-            h["accelerations"] = np.empty((n, 2)); h["masses"] = np.empty((n, 1))
-            h["inverse_masses"] = np.empty((n, 1)); h["temperatures"] = np.empty((n, 1))
-            h["radii"] = np.empty((n, 1), dtype=np.int64)
+        if n != self._host["positions"].shape[0]:
+            self._bind_host(n)
         _capi.check(self._lib, self._lib.psim_download(
             self._ctx, self._ptr("positions"), self._ptr("velocities"), self._ptr("accelerations"),
             self._ptr("masses"), self._ptr("inverse_masses"), self._ptr("temperatures"), self._ptr("radii")))
@@ -207,12 +258,14 @@ class ParticleSystem:
     def _calculate_gravity(self):
         """particle_system.py:409-437 (main.py:151 primes a(0) with it)."""
         self._sync_config()
+        self._sync_state()
         _capi.check(self._lib, self._lib.psim_prime_gravity(self._ctx))
         self._stale = True
 
     def update(self, steps: int = 1):
         """particle_system.py:518-563.  `steps` > 1 runs several updates in one call."""
         self._sync_config()
+        self._sync_state()
         _capi.check(self._lib, self._lib.psim_step(self._ctx, int(steps)))
         self._stale = True
         t = (ctypes.c_double * 3)()
@@ -242,6 +295,7 @@ class ParticleSystem:
                         f"New count: {self.num_particles}.")
 
     def _energies(self):
+        self._sync_state()
         out = (ctypes.c_double * 5)()
         _capi.check(self._lib, self._lib.psim_energies(self._ctx, out))
         return list(out)
@@ -287,6 +341,7 @@ class ParticleSystem:
     def brute_force_accelerations(self):
         """All-pairs softened gravity of the current state (O(n^2) cross-check).
         Returns (accelerations (n,2), kernel milliseconds)."""
+        self._sync_state()
         out = np.empty((self.num_particles, 2))
         ms = ctypes.c_double(0.0)
         _capi.check(self._lib, self._lib.psim_brute_force_gravity(
@@ -296,9 +351,11 @@ class ParticleSystem:
     def render_feed(self):
         """What draw() needs, computed on the device (particle_system.py:587-624 up to the
         rasteriser call): (xy int32 (n,2) = int(position), rgba uint8 (n,4))."""
+        self._sync_state()
         n = self.num_particles
-        xy = np.empty((n, 2), dtype=np.int32)
-        rgba = np.empty((n, 4), dtype=np.uint8)
+        if self._feed is None or self._feed[0][1].shape[0] < n:
+            self._feed = (self._host_block(n, 2, np.int32), self._host_block(n, 4, np.uint8))
+        xy, rgba = self._feed[0][1][:n], self._feed[1][1][:n]
         if n:
             _capi.check(self._lib, self._lib.psim_render_feed(
                 self._ctx, xy.ctypes.data_as(ctypes.c_void_p), rgba.ctypes.data_as(ctypes.c_void_p)))
@@ -307,6 +364,7 @@ class ParticleSystem:
     def exact_potential_energy(self):
         """-G sum_{i<j} m_i m_j / sqrt(d^2 + s) over all pairs (O(n^2) diagnostic; the
         reference's own potential energy pairs sibling cells only)."""
+        self._sync_state()
         out = ctypes.c_double(0.0)
         _capi.check(self._lib, self._lib.psim_pair_potential_energy(self._ctx, ctypes.byref(out)))
         return out.value
@@ -376,22 +434,35 @@ class ParticleSystem:
         temperature through the keyframe ramp of constants.py:37-45."""
         import pygame
         xy, rgba = self.render_feed()
-        radii = self.radii
-        for i in range(self.num_particles):
-            c = (int(rgba[i, 0]), int(rgba[i, 1]), int(rgba[i, 2]))
-            if is_glow_pass:
-                c = c + (255,)
-            pygame.draw.circle(screen, c, (int(xy[i, 0]), int(xy[i, 1])), int(radii[i, 0]))
+        # colours, centres and radii become plain Python lists in three vectorised
+        # conversions; the loop only issues the rasteriser calls
+        colours = [tuple(c) for c in (rgba if is_glow_pass else rgba[:, :3]).tolist()]
+        centres = [tuple(c) for c in xy.tolist()]
+        radii = self.radii[:, 0].tolist()
+        circle = pygame.draw.circle
+        for colour, centre, radius in zip(colours, centres, radii):
+            circle(screen, colour, centre, radius)
 
 
 def _make_property(name):
     def getter(self):
         self._refresh()
-        return self._host[name]
+        view = self._host[name].view()
+        view.flags.writeable = False      # an in-place edit would never reach the device: make it raise
+        return view
 
     def setter(self, value):
+        # the reference's attributes are plain arrays: an assignment is seen by the next
+        # update().  Here it is copied into the page-locked block and uploaded before the
+        # next device call.
         self._refresh()
-        self._host[name] = np.ascontiguousarray(value)
+        value = np.asarray(value)
+        if value.shape != self._host[name].shape:
+            raise ValueError("%s: expected shape %s, got %s" % (name, self._host[name].shape, value.shape))
+        np.copyto(self._host[name], value)
+        if name == "masses":
+            np.copyto(self._host["inverse_masses"], 1.0 / self._host["masses"])
+        self._dirty = True
     return property(getter, setter)
 
 

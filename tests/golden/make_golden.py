@@ -57,6 +57,33 @@ ps_mod, qt_mod, constants = _import_reference()
 DEFAULT_SIM = json.load(open(os.path.join(REF, "config.json")))["simulation"]
 
 
+class LogCapture:
+    """Handler on the reference's own `particle_sim` logger (logger_setup.py:32): keeps
+    (step, level name, message) of every record the step emits (the explosion lines of
+    particle_system.py:683-689, 727-730)."""
+
+    def __init__(self):
+        import logging
+
+        capture = self
+
+        class H(logging.Handler):
+            def emit(self, record):
+                capture.records.append((capture.step, record.levelname, record.getMessage()))
+
+        self.records = []
+        self.step = 0
+        self.handler = H(level=logging.DEBUG)
+        self.logger = logging.getLogger("particle_sim")
+        self.old_level = self.logger.level
+        self.logger.setLevel(logging.DEBUG)
+        self.logger.addHandler(self.handler)
+
+    def close(self):
+        self.logger.removeHandler(self.handler)
+        self.logger.setLevel(self.old_level)
+
+
 class Recorder:
     """Hooks the module-level kernels of the reference to record what a step did."""
 
@@ -183,8 +210,10 @@ def run_case(name, n, sim_overrides, seed, bounds, steps, detail_steps,
     per_step_counts = []
     per_step_coll = []
     ids = np.arange(n, dtype=np.int64)
+    log = LogCapture()
     for step in range(1, steps + 1):
         rec.reset()
+        log.step = step
         pre_n = system.num_particles
         # explosions: record which indices (pre-compaction) explode
         orig_expl = system._handle_explosions
@@ -229,6 +258,9 @@ def run_case(name, n, sim_overrides, seed, bounds, steps, detail_steps,
     out["energies"] = np.array(per_step_energy, dtype=np.float64).reshape(-1, 3)
     out["counts"] = np.array(per_step_counts, dtype=np.int64).reshape(-1, 5)
     out["collision_totals"] = np.array(per_step_coll, dtype=np.float64).reshape(-1, 3)
+    log.close()
+    # the log records of the steps, as the reference's logger produced them
+    out["log_json"] = np.frombuffer(json.dumps(log.records).encode(), dtype=np.uint8)
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
@@ -273,6 +305,12 @@ CASES = {
     # hot start: explosions fire from step 1 on
     "hot300": lambda: run_case("hot300", 300, {"min_temp": 0.85, "max_temp": 1.05},
                                17, (500, 400), 6, range(1, 7)),
+    # nearly everything explodes at once: exploders whose neighbours all explode too take the
+    # warning line (particle_system.py:682-684).  (An exploder with NO particle at all in its
+    # 3x3 cells makes the reference raise IndexError at :680 -- an empty index array is float64 --
+    # so that case has no reference output to record.)
+    "hotall60": lambda: run_case("hotall60", 60, {"min_temp": 0.99, "max_temp": 1.08},
+                                 29, (320, 240), 2, range(1, 3)),
     # fast particles: leave the domain between drift and the wall clamp
     "fast200": lambda: run_case("fast200", 200, {}, 19, (320, 200), 8, range(1, 9),
                                 init_velocity_scale=25.0),

@@ -25,8 +25,7 @@ def make_system(g, library, walk_mode=0, debug=True, **kw):
                        debug=debug, **kw)
     v = g.init_velocities()
     if v is not None:
-        s.velocities[:] = v
-        s.push_state()
+        s.velocities = v
     return s
 
 
@@ -96,46 +95,106 @@ def run_golden_stepwise(name, library, walk_mode=0):
 
 
 def run_against_oracle(n, sim, seed, bounds, steps, library, walk_mode=0, state=None, stage_mask=31,
-                       check_contacts=True, oracle_threads=1, oracle_fast_pow=False):
+                       check_contacts=True, oracle_threads=1, oracle_fast_pow=False, system_class=None,
+                       prime=True, min_contacts=0, min_exploded=0, log_cap=1 << 22):
     """Same seeded inputs through this build and through the C oracle.
     oracle_threads / oracle_fast_pow only make the oracle's gravity loop affordable at
     full benchmark sizes (threads do not change its results; the rsqrt form of x**-1.5
-    changes them by a few ulp, far inside the tolerances below)."""
+    changes them by a few ulp, far inside the tolerances below).
+    system_class: ParticleSystem (default) or its sharded subclass driven through the staged
+    entry points.  prime=False: no priming walk, the first drift uses the given
+    accelerations (zero) -- both sides then drift to bit-identical positions, so the
+    position-only outputs of the first step's contacts (pair list, PE change) are compared
+    bit for bit.  min_contacts / min_exploded: the case must actually exercise those paths."""
     from oracle.oracle import OracleSystem
     rng_a, rng_b = np.random.default_rng(seed), np.random.default_rng(seed)
     o = OracleSystem(n, sim, rng_a, bounds, state=state, stage_mask=stage_mask)
     o.set_threads(oracle_threads)
     o.set_fast_pow(oracle_fast_pow)
-    s = ParticleSystem(n, dict(sim), rng_b, bounds, library=library, walk_mode=walk_mode, debug=True,
-                       state=state, stage_mask=stage_mask)
-    o.enable_contact_log(1 << 22)
-    o._calculate_gravity()
-    s._calculate_gravity()
-    assert s.counts()["tree_nodes"] == o.num_active_nodes
-    acc_close(s.accelerations, o.accelerations)
+    s = (system_class or ParticleSystem)(n, dict(sim), rng_b, bounds, library=library, walk_mode=walk_mode, debug=True,
+                                         state=state, stage_mask=stage_mask)
+    o.enable_contact_log(log_cap)
+    if prime:
+        o._calculate_gravity()
+        s._calculate_gravity()
+        assert s.counts()["tree_nodes"] == o.num_active_nodes
+        acc_close(s.accelerations, o.accelerations)
+    seen_contacts = seen_exploded = 0
     for step in range(1, steps + 1):
         o.update()
         s.update()
         c = s.counts()
         assert c["particles"] == o.num_particles, step
         assert c["tree_nodes"] == o.num_active_nodes, step
+        seen_contacts += c["contacts"]
+        seen_exploded += c["exploded"]
         if stage_mask & 1:
             assert c["contacts"] == o.n_contacts, step
             assert c["candidates"] == o.n_candidates, step
             if check_contacts:
                 ij, vals = o.contact_log()
                 np.testing.assert_array_equal(s.debug_array("contact_ij"), ij, err_msg="step %d" % step)
+                if not prime and step == 1:
+                    # positions are still bit-identical on both sides: so is everything the
+                    # contacts derive from positions alone (particle_system.py:207-237)
+                    np.testing.assert_array_equal(s.debug_array("contact_vals")[:, 0], vals[:, 0],
+                                                  err_msg="PE change of the first step's contacts")
         np.testing.assert_array_equal(s.debug_array("grid_offsets"), o.grid_offsets)
         np.testing.assert_array_equal(s.debug_array("grid_indices"), o.grid_indices)
         np.testing.assert_array_equal(s.debug_array("exploded"), o.exploded)
         np.testing.assert_allclose(s.positions, o.positions, rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(s.velocities, o.velocities, rtol=1e-8, atol=1e-12)
         np.testing.assert_allclose(s.temperatures, o.temperatures, rtol=1e-9, atol=1e-15)
+    assert seen_contacts >= min_contacts and seen_exploded >= min_exploded, (seen_contacts, seen_exploded)
     e_s = np.array(s.get_energies())
     e_o = np.array([o.get_total_kinetic_energy(), o.get_total_potential_energy(), o.get_total_thermal_energy()])
     np.testing.assert_allclose(e_s, e_o, rtol=1e-8)
     s.close()
     return s, o
+
+
+def check_explosion_log(name, library, walk_mode=0):
+    """The log records of the explosion stage (particle_system.py:683-689, 727-730) against
+    the ones the reference's own `particle_sim` logger produced for the same fixture: level,
+    text and order, step by step."""
+    import json
+    import logging
+    g = load_golden(name)
+    want = [tuple(r) for r in json.loads(bytes(g["log_json"]).decode())]
+    got = []
+    state = {"step": 0}
+
+    class Capture(logging.Handler):
+        def emit(self, record):
+            got.append((state["step"], record.levelname, record.getMessage()))
+
+    lg = logging.getLogger("particle_sim")
+    handler, old_level, old_prop = Capture(level=logging.DEBUG), lg.level, lg.propagate
+    s = make_system(g, library, walk_mode)       # (its constructor logs too: not captured)
+    s._calculate_gravity()
+    lg.addHandler(handler)
+    lg.setLevel(logging.DEBUG)
+    lg.propagate = False
+    try:
+        for step in range(1, g.steps + 1):
+            state["step"] = step
+            s.update()
+    finally:
+        lg.removeHandler(handler)
+        lg.setLevel(old_level)
+        lg.propagate = old_prop
+    s.close()
+    assert len(want) > 0
+    assert got == want
+
+
+def c4_state(n, seed=42):
+    """the dense stress recipe at n particles: a uniform disk at 4x the default density
+    (64 Mi particles: R = 73078 in 150000 x 150000), at rest, temperatures U[0.5, 0.9] so
+    that collision heating pushes particles past the explosion threshold"""
+    import bench
+    label, n, bounds, state, mask = bench.workload("c4", n)
+    return bounds, state
 
 
 def clustered_state(n, bounds, seed, clusters, per, spread):

@@ -49,3 +49,23 @@ def run_ranks(world, backend, library, name, steps, timeout=240):
 def test_sharded_equals_unsharded(world, name, steps):
     subprocess.check_call(["make", "-s", "-C", HOSTLOOP_DIR])
     run_ranks(world, "gloo", HOSTLOOP, name, steps)
+
+
+def test_bench_gpus_2_starts_two_ranks_and_prints_one_line():
+    """`bench.py --gpus 2` with no launcher in the environment starts its two ranks itself
+    (here: the host-loop build over gloo, the default 2000-particle workload) and rank 0
+    prints exactly one JSON line with n_gpus == 2"""
+    import json
+    subprocess.check_call(["make", "-s", "-C", HOSTLOOP_DIR])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "1", "--workload", "c0", "--library", HOSTLOOP, "--backend", "gloo",
+                          "--walk-mode", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "strong"
+    assert rec["value"] > 0 and len(rec["roofline"]["kernel_ms_per_rank"]) == 2
+    assert "cpu_baseline" not in rec

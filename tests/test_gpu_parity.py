@@ -73,15 +73,6 @@ def _host_threads():
     return max(1, min(16, os.cpu_count() or 1))
 
 
-def test_full_size_4Mi_all_stages_vs_oracle():
-    """the benchmark's single-GPU configuration itself (4,194,304 particles, bounds
-    90000x45000, seed 42, every stage): prime + one full step against the oracle --
-    node count, grid, contact pair list (about 250k contacts), exploded set bit-exact,
-    state within tolerance"""
-    parity.run_against_oracle(1 << 22, SIM, 42, (90000, 45000), 1, HIP,
-                              oracle_threads=_host_threads(), oracle_fast_pow=True)
-
-
 def test_full_size_1Mi_disk_gravity_only_vs_oracle():
     """the 1Mi uniform-disk gravity-only configuration, two steps"""
     import bench

@@ -175,3 +175,27 @@ def test_checkpoint_restore_continues_bit_identically(tmp_path):
     assert c.num_particles == a.num_particles
     for name in ("positions", "velocities", "accelerations", "temperatures", "masses", "radii"):
         np.testing.assert_array_equal(getattr(c, name), getattr(a, name), err_msg=name)
+
+
+def test_drop_in_launcher_rebinds_the_reference_import(tmp_path):
+    """`python -m psim_amd.drop_in main.py`: a script that imports ParticleSystem the way the
+    reference's main.py does (main.py:9) gets this build's class, with no edit to the script;
+    the script's own sibling modules still resolve"""
+    (tmp_path / "constants.py").write_text("WIDTH, HEIGHT = 640, 480\n")
+    (tmp_path / "main.py").write_text(
+        "import constants\n"
+        "from particle_system import ParticleSystem\n"
+        "result = (ParticleSystem.__module__, constants.WIDTH, __name__)\n")
+    from psim_amd import drop_in
+    import sys
+    saved = sys.modules.pop("particle_system", None), sys.modules.pop("constants", None)
+    try:
+        ns = drop_in.run(str(tmp_path / "main.py"))
+    finally:
+        for name, mod in zip(("particle_system", "constants"), saved):
+            sys.modules.pop(name, None)
+            if mod is not None:
+                sys.modules[name] = mod
+        if str(tmp_path) in sys.path:
+            sys.path.remove(str(tmp_path))
+    assert ns["result"] == ("psim_amd.particle_system", 640, "__main__")

@@ -22,9 +22,59 @@ def build_hostloop():
     subprocess.check_call(["make", "-s", "-C", HOSTLOOP_DIR])
 
 
-@pytest.mark.parametrize("name", ["tiny64", "dense256", "dense400", "hot300", "fast200"])
+@pytest.mark.parametrize("name", ["tiny64", "dense256", "dense400", "hot300", "fast200", "hotall60"])
 def test_golden_stepwise(name):
     parity.run_golden_stepwise(name, HOSTLOOP, walk_mode=1)
+
+
+@pytest.mark.parametrize("name", ["hot300", "hotall60"])
+def test_explosion_log_lines_match_the_reference(name):
+    """info line per explosion in ascending particle index, warning line when every
+    neighbour explodes too, one "removed" line per step (particle_system.py:683-689, 727-730)"""
+    parity.check_explosion_log(name, HOSTLOOP, walk_mode=1)
+
+
+def test_first_step_contact_outputs_bit_exact_without_priming():
+    n = 20000
+    bounds, st = parity.c4_state(n)
+    st = dict(st, velocities=np.random.default_rng(3).standard_normal((n, 2)) * 2.0)
+    parity.run_against_oracle(n, SIM, 1, bounds, 2, HOSTLOOP, walk_mode=1, state=st, prime=False, min_contacts=2000)
+
+
+def test_assigned_arrays_reach_the_next_step_and_views_are_read_only():
+    """`ps.velocities = v` is seen by the next update() (the reference's attributes are plain
+    arrays); an in-place edit of a handed-out view raises instead of being lost"""
+    n, bounds = 800, (700, 500)
+    a = ParticleSystem(n, dict(SIM), np.random.default_rng(2), bounds, library=HOSTLOOP, walk_mode=1)
+    b = ParticleSystem(n, dict(SIM), np.random.default_rng(2), bounds, library=HOSTLOOP, walk_mode=1)
+    c = ParticleSystem(n, dict(SIM), np.random.default_rng(2), bounds, library=HOSTLOOP, walk_mode=1)
+    with pytest.raises(ValueError):
+        a.velocities[0, 0] = 1.0
+    with pytest.raises(ValueError):
+        a.velocities = np.zeros((n + 1, 2))
+    v = np.random.default_rng(9).standard_normal((n, 2))
+    for s in (a, b, c):
+        s._calculate_gravity()
+    a.velocities = v
+    with b.editing() as arrays:
+        arrays["velocities"][:] = v
+    for s in (a, b, c):
+        s.update()
+    assert np.array_equal(a.positions, b.positions)
+    assert not np.array_equal(a.positions, c.positions)
+    assert abs(a.get_total_kinetic_energy() - b.get_total_kinetic_energy()) == 0.0
+
+
+def test_walk_counts_after_explosions():
+    """the counting walk runs over the tree as it was built (before the explosions of the
+    same step removed particles)"""
+    g = parity.load_golden("hot300")
+    s = parity.make_system(g, HOSTLOOP, 1)
+    s._calculate_gravity()
+    s.update()
+    assert s.counts()["exploded"] > 30
+    visits, inter = s.walk_counts()
+    assert visits > inter > g.n * 20
 
 
 def test_default_run_first_steps():

@@ -11,7 +11,7 @@ import pytest
 from conftest import load_golden
 from oracle.oracle import OracleSystem
 
-CASES = ["tiny64", "dense256", "dense400", "hot300", "fast200"]
+CASES = ["tiny64", "dense256", "dense400", "hot300", "fast200", "hotall60"]
 TREE_KEYS = ["int_depth", "int_path", "int_mass", "int_comx", "int_comy",
              "leaf_depth", "leaf_path", "leaf_particle"]
 

@@ -21,14 +21,9 @@ if dense_hot:
     # the dense cold-collapse stress case: a uniform disk at 4x the default density (64 Mi
     # particles: R = 73078 in 150000 x 150000), at rest, temperatures U[0.5, 0.9] so that
     # collision heating pushes particles past the explosion threshold
-    from bench import disk_state
-    radius = float(np.sqrt(n / (np.pi * 4e-3)))
-    side = 2.0 * radius * 1.0263
-    bounds = (side, side)
-    sim = dict(SIM, min_temp=0.5, max_temp=0.9)
-    rng = np.random.default_rng(42)
-    state = disk_state(n, bounds, radius, rng)
-    state["temperatures"] = rng.uniform(0.5, 0.9, (n, 1))
+    import bench
+    label, n, bounds, state, mask = bench.workload("c4", n)
+    sim = dict(SIM)
     ps = ParticleSystem(n, sim, np.random.default_rng(42), bounds, state=state)
 else:
     side = float(np.sqrt(n / 1e-3))            # 1e-3 particles per square pixel, as config.json
