@@ -202,6 +202,16 @@ int psim_render_feed(psim_context* ctx, int32_t* xy_out, uint8_t* rgba_out);
  * -G sum_{i<j} m_i m_j / sqrt(d_ij^2 + s) of the current state, O(n^2) FP64. */
 int psim_pair_potential_energy(psim_context* ctx, double* out);
 
+/* No counterpart in the reference.  psim_pair_potential_energy for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): same kernels, same result bit for bit, but every intermediate (one row
+ * sum per particle, the reduction's partial sums) lives in a fixed device array inside the
+ * library (2 MiB + 8 KiB per GPU, held until the process ends) and the call makes no
+ * hipMalloc / hipFree or other allocating call.  At most 262,144 particles: more is
+ * PSIM_ERR_INVALID with a message naming the limit.  All contexts on one GPU share that
+ * array: calls that overlap in time on the same GPU race (calls on different GPUs do not). */
+int psim_pair_potential_energy_noalloc(psim_context* ctx, double* out);
+
 /* parity hooks: copy a named internal device array to the host.
  * psim_debug_size returns the element count (or < 0 for an unknown name);
  * psim_debug_fetch copies min(bytes, size) bytes.  Names: key perm L owned base

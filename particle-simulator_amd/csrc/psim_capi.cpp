@@ -10,6 +10,7 @@
 #include "../../include/psim.h"
 
 #include <algorithm>
+#include <mutex>
 #include <random>
 #include <stdio.h>
 #include <stdlib.h>
@@ -58,6 +59,46 @@ struct psim_context {
     int device;
     psim::Sim* sim;
 };
+
+// ---- scratch of psim_pair_potential_energy_noalloc: one row sum per particle, then the
+// reduction's partial sums and its result.  Device memory that exists from the moment the
+// library is loaded on a GPU until the process ends (2 MiB + 8 KiB on every GPU used).
+namespace {
+constexpr int64_t kNoallocMaxParticles = 1 << 18;
+constexpr size_t kNoallocWords = (size_t)kNoallocMaxParticles + psim::be::kReduceBlocks + 8;
+#if defined(PSIM_HOSTLOOP)
+double scratch[kNoallocWords];
+#else
+// In host code this name is only a stand-in for the device array: the array's address on a
+// given GPU comes from hipGetSymbolAddress (each GPU holds its own copy at its own address).
+static __device__ __align__(256) double scratch[kNoallocWords];
+#endif
+std::mutex g_scratch_lock;
+double* g_scratch_ptr[64] = {};      // per device ordinal
+
+// called with `device` current (psim_create: the library's set-up call for a device)
+void resolve_scratch(int device)
+{
+    if (device < 0 || device >= 64) throw std::invalid_argument("psim: device ordinal out of range");
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (g_scratch_ptr[device]) return;
+#if defined(PSIM_HOSTLOOP)
+    g_scratch_ptr[device] = scratch;
+#else
+    void* p = nullptr;
+    PSIM_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) throw std::runtime_error("psim: hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[device] = static_cast<double*>(p);
+#endif
+}
+double* scratch_of(int device)
+{
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    double* p = (device >= 0 && device < 64) ? g_scratch_ptr[device] : nullptr;
+    if (!p) throw std::runtime_error("psim: scratch array not resolved for this device");
+    return p;
+}
+}  // namespace
 
 static thread_local std::string g_err;
 
@@ -108,6 +149,7 @@ int psim_create(const psim_config* cfg, int device_ordinal, psim_context** out)
 {
     PSIM_TRY(cfg && out, {
         use_device(device_ordinal);
+        resolve_scratch(device_ordinal);
         psim_context* c = new psim_context;
         c->device = device_ordinal;
         c->sim = nullptr;
@@ -475,6 +517,35 @@ static void pair_potential_impl(psim_context* ctx, double* out)
 int psim_pair_potential_energy(psim_context* ctx, double* out)
 {
     PSIM_TRY(ctx && out, pair_potential_impl(ctx, out))
+}
+
+// The same computation as pair_potential_impl with every intermediate in the library's
+// file-scope device array: no hipMalloc / hipFree, no allocating call of any kind.
+static void pair_potential_noalloc_impl(psim_context* ctx, double* out)
+{
+    use_device(ctx->device);
+    psim::Sim* s = ctx->sim;
+    *out = 0.0;
+    if (s->n > kNoallocMaxParticles)
+        throw std::invalid_argument("psim_pair_potential_energy_noalloc: " + std::to_string(s->n) +
+                                    " particles, the fixed scratch array holds at most " +
+                                    std::to_string(kNoallocMaxParticles));
+    if (s->n == 0) return;
+    double* const base = scratch_of(ctx->device);     // the array's address on this GPU
+    double* const rows = base;
+    double* const partial = base + kNoallocMaxParticles;
+    double* const result = partial + psim::be::kReduceBlocks;
+    // (every word read below is written first by this call: nothing has to start at zero)
+    psim::be::launch(s->st, s->n, psim::PairPotentialRow{s->n, s->pos.p, s->mass.p, s->cfg.softening, rows});
+    psim::be::reduce_sum_f64(s->st, rows, (uint64_t)s->n, partial, result);
+    double sum = 0.0;
+    s->readback(&sum, result, 8);
+    *out = -0.5 * s->cfg.gravity_constant * sum;
+}
+
+int psim_pair_potential_energy_noalloc(psim_context* ctx, double* out)
+{
+    PSIM_TRY(ctx && out, pair_potential_noalloc_impl(ctx, out))
 }
 
 int psim_stage_times(psim_context* ctx, double out_ms[8])

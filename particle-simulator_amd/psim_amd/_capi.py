@@ -27,7 +27,7 @@ EXPORTS = [
     "psim_stage_build", "psim_stage_gravity", "psim_stage_kick_collide", "psim_stage_conduction",
     "psim_stage_finish", "psim_brute_force_gravity", "psim_render_feed", "psim_pair_potential_energy",
     "psim_stage_conduction_exchanges", "psim_stage_settle_positions", "psim_time_walk",
-    "psim_stage_detect", "psim_stage_settle_positions_from"
+    "psim_stage_detect", "psim_stage_settle_positions_from", "psim_pair_potential_energy_noalloc",
 ]
 
 
@@ -114,6 +114,7 @@ def load(path=None):
     L.psim_brute_force_gravity.argtypes = [vp, vp, c_dp]
     L.psim_render_feed.argtypes = [vp, vp, vp]
     L.psim_pair_potential_energy.argtypes = [vp, c_dp]
+    L.psim_pair_potential_energy_noalloc.argtypes = [vp, c_dp]
     L.psim_last_error.restype = ctypes.c_char_p
     L.psim_version.restype = ctypes.c_char_p
     for name in EXPORTS:

@@ -1,0 +1,57 @@
+"""The entry point that allocates nothing (psim_pair_potential_energy_noalloc), called through
+the C ABI on the GPU and checked bit for bit against psim_pair_potential_energy: two calls
+in a row, the second on a smaller input (the fixed scratch array keeps the first call's
+contents), then the size limit."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from psim_amd import _capi
+from psim_amd.particle_system import ParticleSystem
+
+pytestmark = pytest.mark.gpu
+
+SIM = dict(particle_count=0, min_mass=5.0, max_mass=20.0, gravity_constant=0.01, softening_factor=10,
+           barnes_hut_theta=0.5, min_temp=0.05, max_temp=0.1, heat_transfer_coefficient=0.1,
+           coefficient_of_restitution=0.5, grid_cell_size_multiplier=10.0, position_correction_factor=1.05,
+           collision_solver_iterations=1, explosion_efficiency=0.5, thermal_damping_factor=0.0005)
+
+
+def both(ps):
+    L = ps._lib
+    a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _capi.check(L, L.psim_pair_potential_energy(ps._ctx, ctypes.byref(a)))
+    _capi.check(L, L.psim_pair_potential_energy_noalloc(ps._ctx, ctypes.byref(b)))
+    return a.value, b.value
+
+
+def test_no_alloc_entry_point_matches_on_two_calls_in_a_row():
+    big = ParticleSystem(50000, dict(SIM), np.random.default_rng(1), (7000, 7000))
+    small = ParticleSystem(3001, dict(SIM), np.random.default_rng(2), (1700, 1700))
+    a, b = both(big)
+    assert a == b and a < 0.0                      # bit-identical (same kernels, same association)
+    a2, b2 = both(small)                           # smaller input on the scratch the first call left
+    assert a2 == b2 and a2 < 0.0 and a2 != a
+    # and against NumPy, to the tolerance of the existing entry point's own test (rtol 1e-12)
+    pos, m = small.positions, small.masses[:, 0]
+    d = pos[:, None, :] - pos[None, :, :]
+    d2 = (d ** 2).sum(-1)
+    iu = np.triu_indices(len(m), 1)
+    want = -(0.01 * m[iu[0]] * m[iu[1]] / np.sqrt(d2[iu] + 10)).sum()
+    np.testing.assert_allclose(b2, want, rtol=1e-12)
+    # the same context again after the other one used the array
+    assert both(big) == (a, a)
+    # sizes beyond the fixed array are refused with a clear message
+    over = ParticleSystem((1 << 18) + 1, dict(SIM), np.random.default_rng(3), (16000, 16000))
+    out = ctypes.c_double(7.0)
+    rc = over._lib.psim_pair_potential_energy_noalloc(over._ctx, ctypes.byref(out))
+    assert rc == -1 and b"at most 262144" in over._lib.psim_last_error()
+    edge = ParticleSystem(1 << 18, dict(SIM), np.random.default_rng(4), (16000, 16000))
+    a3, b3 = both(edge)
+    assert a3 == b3
+    # an empty system
+    empty = ParticleSystem(0, dict(SIM), np.random.default_rng(5), (100, 100))
+    assert both(empty) == (0.0, 0.0)
+    for s in (big, small, over, edge, empty):
+        s.close()
