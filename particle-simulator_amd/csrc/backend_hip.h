@@ -862,13 +862,15 @@ template <bool COUNT, bool FOLD, bool WIDE>
 __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
-    const double* __restrict__ inv_mass, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,
+    const uint32_t* __restrict__ order, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,
     double softening, unsigned long long* __restrict__ counters)
 {
-    // targets are the sorted particles [s_begin, s_end); results go to acc_out[particle
-    // index] or, for a sharded walk, to acc_out[sorted position]
-    const int64_t s = s_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = s < s_end;
+    // targets are the entries [s_begin, s_end) of `order` (sorted positions in the order the
+    // walk groups them); results go to acc_out[particle index] or, for a sharded walk, to
+    // acc_out[entry number]
+    const int64_t k_target = s_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = k_target < s_end;
+    const uint32_t s = live ? (order ? order[k_target] : (uint32_t)k_target) : 0u;     // (no order: the sorted particles themselves)
     double px = 0.0, py = 0.0;
     if (live) { vec2 p = spos[s]; px = p.x; py = p.y; }
     uint32_t until = live ? 0u : 0xffffffffu;
@@ -917,12 +919,13 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     }
     if (live) {
         uint32_t p = perm[s];
-        double gm = g_const * smass[s];
-        double im = inv_mass[p];
+        double m = smass[s];
+        double gm = g_const * m;
+        double im = 1.0 / m;          // = the stored inverse mass (particle_system.py:374), bit for bit
         vec2 a;
         a.x = (gm * ax) * im;
         a.y = (gm * ay) * im;
-        acc_out[sorted_out ? (uint32_t)s : p] = a;
+        acc_out[sorted_out ? (uint32_t)k_target : p] = a;
     }
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)visits);
@@ -947,7 +950,7 @@ template <int K, bool FOLD, bool WIDE>
 __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
-    const double* __restrict__ inv_mass, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,
+    const uint32_t* __restrict__ order, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,
     double softening, uint32_t nchunks, uint32_t* __restrict__ chunk_counter)
 {
     static_assert(K >= 2 && K <= 4, "two to four walks per wave");
@@ -985,10 +988,10 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
     uint32_t until[K], j[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int64_t s = s0 + 64 * k;
-        const bool live = s < s_end;
+        const int64_t kt = s0 + 64 * k;          // entry of `order`: the k-th group's target of this lane
+        const bool live = kt < s_end;
         px[k] = 0.0; py[k] = 0.0; ax[k] = 0.0; ay[k] = 0.0;
-        if (live) { vec2 p = spos[s]; px[k] = p.x; py[k] = p.y; }
+        if (live) { vec2 p = spos[order[kt]]; px[k] = p.x; py[k] = p.y; }
         until[k] = live ? 0u : 0xffffffffu;
         // a group that lies beyond the range altogether is not walked
         j[k] = __builtin_amdgcn_ballot_w64(live) ? 0u : total_elems;
@@ -1048,15 +1051,17 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
         while (j[k] < total_elems) j[k] = trip(fetch(j[k]), j[k], px[k], py[k], ax[k], ay[k], until[k]);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int64_t s = s0 + 64 * k;
-        if (s < s_end) {
+        const int64_t kt = s0 + 64 * k;
+        if (kt < s_end) {
+            const uint32_t s = order[kt];
             uint32_t p = perm[s];
-            double gm = g_const * smass[s];
-            double im = inv_mass[p];
+            double m = smass[s];
+            double gm = g_const * m;
+            double im = 1.0 / m;      // = the stored inverse mass (particle_system.py:374), bit for bit
             vec2 a;
             a.x = (gm * ax[k]) * im;
             a.y = (gm * ay[k]) * im;
-            acc_out[sorted_out ? (uint32_t)s : p] = a;
+            acc_out[sorted_out ? (uint32_t)kt : p] = a;
         }
     }
     if (!chunk_counter) return;
@@ -1065,11 +1070,14 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
 
 template <int K>
 inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
-                              const vec2* spos, const double* smass, const uint32_t* perm, const double* inv_mass,
+                              const vec2* spos, const double* smass, const uint32_t* perm, const uint32_t* order,
                               vec2* out, bool fold, uint32_t w2_lo, double theta2, double g_const, double softening,
                               uint32_t* chunk_counter, int64_t resident_waves, bool force_wide = false)
 {
     if (hi <= lo) return;
+    // (the kernel reads `order` unconditionally: a null check in it costs two scalar registers,
+    // which takes the allocation from 80 to 96)
+    if (!order) throw std::runtime_error("launch_walk_multi: no target order");
     int64_t chunks = (hi - lo + 64 * K - 1) / (64 * K);
     if (chunks > 0x7fffffffLL) throw std::runtime_error("launch_walk_multi: grid too large");
     // chunk_counter (two zero words) + resident_waves > 0: a fixed number of waves share the chunks
@@ -1080,7 +1088,7 @@ inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out,
     const bool wide = force_wide || (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
-                           perm, inv_mass, out, w2_lo, theta2, g_const, softening, (uint32_t)chunks, chunk_counter);
+                           perm, order, out, w2_lo, theta2, g_const, softening, (uint32_t)chunks, chunk_counter);
     };
     if (fold && !wide) go(gravity_walk_multi_kernel<K, true, false>);
     else if (fold) go(gravity_walk_multi_kernel<K, true, true>);
@@ -1091,7 +1099,7 @@ inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out,
 
 template <bool COUNT>
 inline void launch_walk(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
-                        const vec2* spos, const double* smass, const uint32_t* perm, const double* inv_mass, vec2* out,
+                        const vec2* spos, const double* smass, const uint32_t* perm, const uint32_t* order, vec2* out,
                         bool fold, uint32_t w2_lo, double theta2, double g_const, double softening,
                         unsigned long long* counters, bool force_wide = false)
 {
@@ -1101,7 +1109,7 @@ inline void launch_walk(Stream st, int64_t lo, int64_t hi, int sorted_out, const
     const bool wide = force_wide || (uint64_t)total * sizeof(NodeRec) >= (1ull << 32);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
-                           perm, inv_mass, out, w2_lo, theta2, g_const, softening, counters);
+                           perm, order, out, w2_lo, theta2, g_const, softening, counters);
     };
     if (fold && !wide) go(gravity_walk_wave_kernel<COUNT, true, false>);
     else if (fold) go(gravity_walk_wave_kernel<COUNT, true, true>);

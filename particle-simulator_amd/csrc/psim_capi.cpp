@@ -26,11 +26,12 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     uint32_t total = (uint32_t)(n + n_internal);
     double theta2 = cfg.theta * cfg.theta;          // particle_system.py:88 theta * theta * dist_sq
 #if !defined(PSIM_HOSTLOOP)
+    join_hilbert();
     if (cfg.walk_mode == 0 || cfg.walk_mode == 3) {
         // default: two walks per wave (3: with 64-bit element offsets forced, as on arrays of 4 GiB and more)
         be::launch_walk_multi<2>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
                                  (const double*)smass.p, (const uint32_t*)perm[sorted_key].p,
-                                 (const double*)inv_mass.p, out, walk_fold, (uint32_t)w2_cmp_bits, theta2,
+                                 walk_order(), out, walk_fold, (uint32_t)w2_cmp_bits, theta2,
                                  cfg.gravity_constant, cfg.softening, walk_ctr.p, walk_resident_waves(),
                                  cfg.walk_mode == 3);
         return;
@@ -38,7 +39,7 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     if (cfg.walk_mode == 2 || cfg.walk_mode == 4) {
         // one walk per wave (the kernel the visit / interaction counts are taken with)
         be::launch_walk<false>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
-                               (const double*)smass.p, (const uint32_t*)perm[sorted_key].p, (const double*)inv_mass.p,
+                               (const double*)smass.p, (const uint32_t*)perm[sorted_key].p, walk_order(),
                                out, walk_fold, (uint32_t)w2_cmp_bits, theta2, cfg.gravity_constant, cfg.softening,
                                (unsigned long long*)nullptr, cfg.walk_mode == 4);
         return;
@@ -351,13 +352,14 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     double theta2 = s->cfg.theta * s->cfg.theta;
     psim::DevBuf<psim::vec2> scratch;
     scratch.ensure((size_t)tn);
+    s->join_hilbert();
 #if !defined(PSIM_HOSTLOOP)
     psim::DevBuf<unsigned long long> cnt;
     cnt.ensure(32);
     psim::be::dev_memset(s->st, cnt.p, 0, 256);
     psim::be::launch_walk<true>(s->st, (int64_t)0, tn, 0, (const psim::NodeRec*)s->rec.p, total,
                                 (const psim::vec2*)s->spos.p, (const double*)s->smass.p,
-                                (const uint32_t*)s->perm[s->sorted_key].p, (const double*)s->inv_mass.p, scratch.p,
+                                (const uint32_t*)s->perm[s->sorted_key].p, s->walk_order(), scratch.p,
                                 s->walk_fold, (uint32_t)s->w2_cmp_bits, theta2, s->cfg.gravity_constant,
                                 s->cfg.softening, cnt.p);
     unsigned long long h[32];
@@ -401,11 +403,12 @@ static void time_walk_impl(psim_context* ctx, int32_t reps, double slots_per_sim
     double theta2 = s->cfg.theta * s->cfg.theta;
     psim::DevBuf<psim::vec2> scratch;
     scratch.ensure((size_t)tn);
+    s->join_hilbert();
     int64_t resident = (int64_t)(psim::be::compute_units() * 4 * slots_per_simd);
     auto once = [&]() {
         psim::be::launch_walk_multi<2>(s->st, (int64_t)0, tn, 0, (const psim::NodeRec*)s->rec.p, total,
                                        (const psim::vec2*)s->spos.p, (const double*)s->smass.p,
-                                       (const uint32_t*)s->perm[s->sorted_key].p, (const double*)s->inv_mass.p, scratch.p,
+                                       (const uint32_t*)s->perm[s->sorted_key].p, s->walk_order(), scratch.p,
                                        s->walk_fold, (uint32_t)s->w2_cmp_bits, theta2, s->cfg.gravity_constant,
                                        s->cfg.softening, s->walk_ctr.p, resident);
     };

@@ -94,6 +94,11 @@ public:
     DevBuf<uint32_t> perm[2];
     DevBuf<vec2> spos;
     DevBuf<double> smass;
+    // order in which the walk groups its targets: sorted positions along a Hilbert curve
+    // (hkey = curve index of each sorted particle, hord = the sorted positions, both sorted by hkey)
+    DevBuf<uint32_t> hkey[2], hord[2];
+    int sorted_h = 0;
+    bool hilbert_ready = false;     // hord[sorted_h] describes the current tree
     DevBuf<int8_t> L;
     DevBuf<uint32_t> owned, base;
     DevBuf<NodeRec> rec;
@@ -193,7 +198,7 @@ public:
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
     be::Stream st2;
-    be::Event ev_drift, ev_side, ev_walk;
+    be::Event ev_drift, ev_side, ev_walk, ev_gathered, ev_hilbert;
     bool walk_in_flight = false;       // a walk was submitted this step and has not been seen to finish
     // Scans on the side lane use small workgroups only while the walk is still holding its wave
     // slots; once it has finished the larger ones are faster (about 2x at tens of millions of items).
@@ -244,6 +249,8 @@ public:
         be::event_destroy(ev_drift);
         be::event_destroy(ev_side);
         be::event_destroy(ev_walk);
+        be::event_destroy(ev_gathered);
+        be::event_destroy(ev_hilbert);
         be::stream_destroy(st2);
     }
 
@@ -259,6 +266,8 @@ public:
         ev_drift = be::event_create();
         ev_side = be::event_create();
         ev_walk = be::event_create();
+        ev_gathered = be::event_create();
+        ev_hilbert = be::event_create();
         red_tmp.ensure(be::kReduceBlocks);
         red_out.ensure(8);
         depth_off.ensure(40);
@@ -500,7 +509,37 @@ public:
             }
             skey = key[sorted_key].p;
             sperm = perm[sorted_key].p;
-            be::launch(st, n, GatherTree{n, sperm, pos.p, mass.p, spos.p, smass.p});
+            {
+                GatherTree gt;
+                gt.n = n; gt.perm = sperm; gt.pos = pos.p; gt.mass = mass.p; gt.spos = spos.p; gt.smass = smass.p;
+                gt.hkey = nullptr; gt.hval = nullptr; gt.hscale = 0.0;
+                if (walk_uses_order()) {
+                    for (int i = 0; i < 2; ++i) { hkey[i].ensure(c); hord[i].ensure(c); }
+                    double side = cfg.bounds_w > cfg.bounds_h ? cfg.bounds_w : cfg.bounds_h;
+                    gt.hkey = hkey[0].p; gt.hval = hord[0].p; gt.hscale = 4096.0 / side;
+                }
+                be::launch(st, n, gt);
+                hilbert_ready = false;
+                if (walk_uses_order()) {
+                    // Sorted by curve index (stable: particles sharing a curve cell keep their Z
+                    // order).  Nothing but the walk needs it, so it goes to the second stream when
+                    // there is one, submitted here so that the host's launch work is hidden behind
+                    // the kernels the main stream still has queued.  (Should this attempt's Morton
+                    // sort turn out incomplete, the next attempt submits it again behind this one.)
+                    uint32_t* hk[2] = {hkey[0].p, hkey[1].p};
+                    uint32_t* hv[2] = {hord[0].p, hord[1].p};
+                    if (cfg.overlap != 0) {
+                        sort_tmp2.ensure(be::sort_temp_words(c));
+                        be::event_record(ev_gathered, st);
+                        be::stream_wait(st2, ev_gathered);
+                        sorted_h = be::radix_sort_pairs<uint32_t>(st2, hk, hv, (uint64_t)n, 0, 24, sort_tmp2.p);
+                        be::event_record(ev_hilbert, st2);
+                    } else {
+                        sorted_h = be::radix_sort_pairs<uint32_t>(st, hk, hv, (uint64_t)n, 0, 24, sort_tmp.p);
+                    }
+                    hilbert_ready = true;
+                }
+            }
             be::launch(st, n, TreeLinks{n, skey, L.p, owned.p});
             be::exclusive_scan_u32(st, owned.p, base.p, (uint64_t)n, scan_tmp.p, counters.p);
             uint32_t five[5];
@@ -536,7 +575,11 @@ public:
             be::launch(st, (int64_t)m + 1, SegmentOffsets{(int64_t)m, node_depth[sd].p, depth_off.p, (uint32_t)(kKeyLevels + 1)});
             readback(depth_off_host, depth_off.p, sizeof(int32_t) * (kKeyLevels + 2));
             // one launch per depth, deepest first (folding the small top levels into one
-            // single-workgroup launch was measured and is no faster than their launches)
+            // single-workgroup launch was measured and is no faster than their launches; a single
+            // bottom-up pass in which the last child to finish forms its parent was measured too:
+            // records passed between workgroups inside one launch have to bypass the per-XCD L2
+            // caches, and the pass took 440 us at 4 Mi particles against 300 us for the depth
+            // sort plus these launches)
             TreeCom t0;
             t0.count = 0; t0.ids = node_id[sd].p; t0.depth = 0; t0.ch = node_children(); t0.rec = rec.p;
             for (int d = kMaxInternalDepth; d >= 0; --d) {
@@ -545,6 +588,23 @@ public:
             }
         }
         tree_valid = true;
+    }
+
+    // the wave-cooperative walks take their targets in Hilbert order; the one-lane-per-particle
+    // walk (and the test-only host-loop build, which has no other) in sorted order
+    bool walk_uses_order() const
+    {
+#if defined(PSIM_HOSTLOOP)
+        return false;
+#else
+        return cfg.walk_mode != 1;
+#endif
+    }
+    const uint32_t* walk_order() const { return hilbert_ready ? hord[sorted_h].p : nullptr; }
+    // the main stream may use walk_order() after this
+    void join_hilbert()
+    {
+        if (hilbert_ready && cfg.overlap != 0) be::stream_wait(st, ev_hilbert);
     }
 
     NodeChildren node_children() const
@@ -1236,7 +1296,7 @@ public:
     }
     void stage_kick_collide(const vec2* acc_sorted)
     {
-        be::launch(st, n, ScatterSorted{n, perm[sorted_key].p, acc_sorted, acc2.p});
+        be::launch(st, n, ScatterSorted{n, perm[sorted_key].p, walk_order(), acc_sorted, acc2.p});
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
         settle_positions();
