@@ -147,6 +147,25 @@ inline void mailbox_fetch(Stream st, Mailbox& m, void* dst, const void* a, uint3
     memcpy(dst, (const void*)m.host, (size_t)(na + nb) * 4);
 }
 
+// One wave that does nothing for about `microseconds` (bounded by the constant-rate clock).
+// The second stream starts with it when it is released together with the walk: work of that
+// stream that reaches the dispatcher before the walk's resident waves are in place was seen
+// to be left without wave slots for the whole walk (a 60 us kernel lasting 3.3 ms).
+__global__ void __launch_bounds__(64) delay_kernel(uint32_t microseconds)
+{
+    const uint64_t t0 = wall_clock64();                 // 100 MHz
+    const uint64_t ticks = (uint64_t)microseconds * 100u;
+    for (int i = 0; i < 4096; ++i) {
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+inline void delay(Stream st, uint32_t microseconds)
+{
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, st, microseconds);
+    PSIM_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------ launch
 template <class F>
 __global__ void __launch_bounds__(256) psim_kernel(int64_t n, F f)

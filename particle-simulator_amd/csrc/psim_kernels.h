@@ -137,7 +137,28 @@ struct SegmentOffsets {
     {
         int64_t lo = (k == 0) ? 0 : (int64_t)keys[k - 1] + 1;
         int64_t hi = (k == n) ? (int64_t)num_segments : (int64_t)keys[k];
+#if defined(PSIM_HOSTLOOP)
         for (int64_t c = lo; c <= hi; ++c) offsets[c] = (int32_t)k;
+#else
+        // A long run of empty segments before k (whole empty grid rows around a disk of
+        // particles: tens of thousands of cells) is filled by the 64 lanes of the wave together;
+        // one lane alone would keep its wave alive for as many stores.
+        constexpr int64_t kOwn = 16;
+        const bool far = hi - lo >= kOwn;
+        if (!far) for (int64_t c = lo; c <= hi; ++c) offsets[c] = (int32_t)k;
+        // (the lanes that run this body may be fewer than 64 in the last wave of the launch)
+        const unsigned long long here = __ballot(1);
+        unsigned long long todo = __ballot(far);
+        const int lane = (int)(threadIdx.x & 63u);
+        const int rank = __popcll(here & ((1ull << lane) - 1ull)), width = __popcll(here);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int64_t l2 = (int64_t)__shfl((long long)lo, src, 64), h2 = (int64_t)__shfl((long long)hi, src, 64);
+            const int32_t v = (int32_t)__shfl((long long)k, src, 64);
+            for (int64_t c = l2 + rank; c <= h2; c += width) offsets[c] = v;
+        }
+#endif
     }
 };
 

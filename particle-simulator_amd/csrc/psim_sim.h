@@ -9,6 +9,9 @@
 #include <string>
 #include <vector>
 #include "psim_kernels.h"
+#if !defined(PSIM_HOSTLOOP)
+#include "psim_tree_hip.h"
+#endif
 
 namespace psim {
 
@@ -104,6 +107,8 @@ public:
     DevBuf<NodeRec> rec;
     DevBuf<uint32_t> node_first, node_last, node_depth[2], node_id[2];
     DevBuf<double> pe_node;
+    DevBuf<uint64_t> far_list;           // nodes the cooperative emit leaves to per-depth passes
+    DevBuf<uint32_t> far_count, emit_words;
     DevBuf<int32_t> depth_off;
     DevBuf<double> w2tab;
     int32_t depth_off_host[40];
@@ -470,6 +475,47 @@ public:
         be::launch(s, 64, FinalMax{left, cur, ctr + 2});
     }
 
+    // The element array by the per-element kernels: leaves, then internal nodes, then the
+    // centres of mass one launch per depth.  (The HIP build normally uses the cooperative
+    // pass of psim_tree_hip.h and comes here only when that pass declines: coinciding
+    // particles below the deepest level, or a tile with too many far-reaching nodes.)
+    void emit_per_element(const uint64_t* skey, uint32_t m)
+    {
+        size_t mm = m ? m : 1;
+        TreeEmitLeaves e;
+        e.n = n; e.L = L.p; e.owned = owned.p; e.base = base.p; e.spos = spos.p; e.smass = smass.p; e.rec = rec.p;
+        e.node_first = node_first.p; e.node_depth = node_depth[0].p; e.node_id = node_id[0].p;
+        be::launch(st, n, e);
+        if (m > 0) {
+            TreeEmitNodes en;
+            en.count = m; en.n = n; en.key = skey; en.L = L.p; en.base = base.p; en.node_first = node_first.p;
+            en.node_depth = node_depth[0].p; en.spos = spos.p; en.smass = smass.p; en.total_elems = (uint32_t)(n + m); en.rec = rec.p; en.root_tag = root_tag();
+            en.node_last = node_last.p;
+            be::launch(st, (int64_t)m, en);
+        }
+        if (m > 0) {
+            sort_tmp.ensure(be::sort_temp_words(mm));
+            uint32_t* dk[2] = {node_depth[0].p, node_depth[1].p};
+            uint32_t* dv[2] = {node_id[0].p, node_id[1].p};
+            int sd = be::radix_sort_pairs<uint32_t>(st, dk, dv, (uint64_t)m, 0, 8, sort_tmp.p);
+            // segments 0..31: depths; segment 32 (kDepthDone): cells finished by TreeEmitNodes
+            be::launch(st, (int64_t)m + 1, SegmentOffsets{(int64_t)m, node_depth[sd].p, depth_off.p, (uint32_t)(kKeyLevels + 1)});
+            readback(depth_off_host, depth_off.p, sizeof(int32_t) * (kKeyLevels + 2));
+            // one launch per depth, deepest first (folding the small top levels into one
+            // single-workgroup launch was measured and is no faster than their launches; a single
+            // bottom-up pass in which the last child to finish forms its parent was measured too:
+            // records passed between workgroups inside one launch have to bypass the per-XCD L2
+            // caches, and the pass took 440 us at 4 Mi particles against 300 us for the depth
+            // sort plus these launches)
+            TreeCom t0;
+            t0.count = 0; t0.ids = node_id[sd].p; t0.depth = 0; t0.ch = node_children(); t0.rec = rec.p;
+            for (int d = kMaxInternalDepth; d >= 0; --d) {
+                int64_t cnt = (int64_t)depth_off_host[d + 1] - depth_off_host[d];
+                if (cnt > 0) be::launch(st, cnt, t0.at_level(node_id[sd].p, d, depth_off_host[d], cnt));
+            }
+        }
+    }
+
     // quadtree.py:177-196 (build) as sort + links + emit + bottom-up COM
     void build_tree()
     {
@@ -555,38 +601,38 @@ public:
         rec.ensure(c + mm);
         node_first.ensure(mm); node_last.ensure(mm); node_depth[0].ensure(mm); node_depth[1].ensure(mm);
         node_id[0].ensure(mm); node_id[1].ensure(mm); pe_node.ensure(mm);
-        TreeEmitLeaves e;
-        e.n = n; e.L = L.p; e.owned = owned.p; e.base = base.p; e.spos = spos.p; e.smass = smass.p; e.rec = rec.p;
-        e.node_first = node_first.p; e.node_depth = node_depth[0].p; e.node_id = node_id[0].p;
-        be::launch(st, n, e);
-        if (m > 0) {
-            TreeEmitNodes en;
-            en.count = m; en.n = n; en.key = skey; en.L = L.p; en.base = base.p; en.node_first = node_first.p;
-            en.node_depth = node_depth[0].p; en.spos = spos.p; en.smass = smass.p; en.total_elems = (uint32_t)(n + m); en.rec = rec.p; en.root_tag = root_tag();
-            en.node_last = node_last.p;
-            be::launch(st, (int64_t)m, en);
-        }
-        if (m > 0) {
-            sort_tmp.ensure(be::sort_temp_words(mm));
-            uint32_t* dk[2] = {node_depth[0].p, node_depth[1].p};
-            uint32_t* dv[2] = {node_id[0].p, node_id[1].p};
-            int sd = be::radix_sort_pairs<uint32_t>(st, dk, dv, (uint64_t)m, 0, 8, sort_tmp.p);
-            // segments 0..31: depths; segment 32 (kDepthDone): cells finished by TreeEmitNodes
-            be::launch(st, (int64_t)m + 1, SegmentOffsets{(int64_t)m, node_depth[sd].p, depth_off.p, (uint32_t)(kKeyLevels + 1)});
-            readback(depth_off_host, depth_off.p, sizeof(int32_t) * (kKeyLevels + 2));
-            // one launch per depth, deepest first (folding the small top levels into one
-            // single-workgroup launch was measured and is no faster than their launches; a single
-            // bottom-up pass in which the last child to finish forms its parent was measured too:
-            // records passed between workgroups inside one launch have to bypass the per-XCD L2
-            // caches, and the pass took 440 us at 4 Mi particles against 300 us for the depth
-            // sort plus these launches)
-            TreeCom t0;
-            t0.count = 0; t0.ids = node_id[sd].p; t0.depth = 0; t0.ch = node_children(); t0.rec = rec.p;
-            for (int d = kMaxInternalDepth; d >= 0; --d) {
-                int64_t cnt = (int64_t)depth_off_host[d + 1] - depth_off_host[d];
-                if (cnt > 0) be::launch(st, cnt, t0.at_level(node_id[sd].p, d, depth_off_host[d], cnt));
+        bool emitted = false;
+#if !defined(PSIM_HOSTLOOP)
+        {
+            // one cooperative pass: elements assembled tile by tile in LDS, centres of mass of
+            // every subtree that ends inside its tile formed there, each element written once
+            const uint32_t tiles = be::emit_tiles(n);
+            far_list.ensure((size_t)tiles * be::kEmitSlots); far_count.ensure(tiles); emit_words.ensure(4);
+            be::dev_memset(st, emit_words.p, 0, 16);
+            be::TreeEmitArgs a;
+            a.n = n; a.key = skey; a.L = L.p; a.base = base.p; a.spos = spos.p; a.smass = smass.p;
+            a.total_elems = (uint32_t)(n + m); a.root_tag = root_tag(); a.rec = rec.p; a.node_first = node_first.p;
+            a.node_last = node_last.p; a.far_list = far_list.p; a.far_count = far_count.p; a.words = emit_words.p;
+            be::launch_tree_emit(st, a);
+            uint32_t w[3];
+            readback(w, emit_words.p, 12);
+            if (w[2] == 0) {
+                // what the tiles left over: the nodes whose subtree reaches beyond their tile
+                be::TreeFarRanges fr;
+                fr.count = (int64_t)tiles * be::kEmitSlots; fr.n = n; fr.far_list = far_list.p; fr.far_count = far_count.p;
+                fr.key = skey; fr.base = base.p; fr.node_first = node_first.p; fr.total_elems = (uint32_t)(n + m);
+                fr.rec = rec.p; fr.node_last = node_last.p;
+                be::launch(st, fr.count, fr);
+                be::TreeComFar f;
+                f.count = (int64_t)tiles * be::kEmitSlots; f.far_list = far_list.p; f.far_count = far_count.p;
+                f.ch = node_children(); f.rec = rec.p;
+                const int dlo = w[0] ? 64 - (int)w[0] : 0, dhi = (int)w[1];
+                for (int d = dhi - 1; d >= dlo; --d) { f.depth = (uint32_t)d; be::launch(st, f.count, f); }
+                emitted = true;
             }
         }
+#endif
+        if (!emitted) emit_per_element(skey, m);
         tree_valid = true;
     }
 
@@ -1141,6 +1187,7 @@ public:
     void start_side_work()
     {
         be::stream_wait(st2, ev_drift);
+        be::delay(st2, 40);          // (lets the walk, released by the same event, take its wave slots first)
         build_grid(st2, sort_tmp2);
         // (in a sharded step the caller may ask for the count pass of its own slab instead: stage_detect)
         if ((cfg.stage_mask & kStageCollisions) && !sharded_step) {

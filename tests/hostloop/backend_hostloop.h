@@ -34,6 +34,7 @@ inline Event event_create() { return 0; }
 inline void event_destroy(Event) {}
 inline void event_record(Event, Stream) {}
 inline void stream_wait(Stream, Event) {}
+inline void delay(Stream, uint32_t) {}
 inline bool event_done(Event) { return true; }
 inline void* host_alloc_pinned(size_t bytes) { return calloc(bytes ? bytes : 16, 1); }
 inline void host_free_pinned(void* p) { free(p); }
