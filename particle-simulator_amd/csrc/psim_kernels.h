@@ -1264,12 +1264,26 @@ struct SegDisplacement {
     double* dseg;
     uint32_t* dmax_bits;       // raised to the largest bound of all slots (float bit pattern)
     uint32_t* zero_word;       // [0] and [5] are cleared here for the counting pass that follows
+    // The same pass tells the re-test which slots it has to look at again: a slot's versioned
+    // positions are a function of the sequence (ordering key, position after) of its
+    // hypothesised contacts.  sig[slot] keeps a 64-bit digest of that sequence from the previous
+    // iteration of the sweep (0 = no contact); changed[slot] is set where the digest differs.
+    const uint64_t* hkeys;
+    const uint64_t* sig;
+    uint64_t* dsig;            // [first adjacency entry of the slot] this iteration's digest (EndIteration moves it to sig)
+    uint8_t* changed;
+    static PSIM_HD PSIM_FORCEINLINE uint64_t mix(uint64_t h)
+    {
+        h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+        return h;
+    }
     PSIM_HD void operator()(int64_t e) const
     {
         if (e == 0) { zero_word[0] = 0u; zero_word[5] = 0u; }
         uint32_t x = (uint32_t)(adj[e] >> 32);
         if (cseg[x] != (int32_t)e) return;
         double x0 = body[x].x, y0 = body[x].y, m = 0.0;
+        uint64_t digest = 0x9e3779b97f4a7c15ull;
         for (int64_t k = e; k < n_adj && (uint32_t)(adj[k] >> 32) == x; ++k) {
             uint32_t h = (uint32_t)adj[k];
             int side = (hsi[h] == x) ? 0 : 1;
@@ -1277,19 +1291,113 @@ struct SegDisplacement {
             double dx = p.x - x0, dy = p.y - y0;
             double d2 = dx * dx + dy * dy;
             m = d2 > m ? d2 : m;
+            uint64_t bx, by;
+            __builtin_memcpy(&bx, &p.x, 8);
+            __builtin_memcpy(&by, &p.y, 8);
+            digest = mix(digest ^ hkeys[h]);
+            digest = mix(digest ^ bx);
+            digest = mix(digest ^ by);
         }
+        if (digest == 0) digest = 1;
         double bound = sqrt(m) * (1.0 + 1e-6) + 1e-9;
         dseg[e] = bound;
         raise_to_u32(dmax_bits, float_bits_at_least(bound));
+        changed[x] = sig[x] != digest ? 1 : 0;
+        dsig[e] = digest;
     }
 };
 
-// Re-test, against the versioned positions, every candidate pair that involves
-// a slot touched by a hypothesised contact.  Element index = cell selector *
-// n_adj + index into the list of touched slots (the nine cells of one touched slot
-// are re-tested by different lanes; the launch covers 20 n_H elements, fewer than
-// 2^32, of which those past the end of the list have nothing to do).  A pair of
-// two touched slots is emitted once, by the lower slot.
+// The slots the previous iteration's hypothesis touched and this one's does not: they are
+// back at their initial positions, which is a change too.
+struct MarkUntouched {
+    int64_t cap;
+    const uint32_t* prev_slots;
+    const uint32_t* n_prev;
+    const int32_t* cseg;
+    uint64_t* sig;
+    uint8_t* changed;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        if (i >= (int64_t)*n_prev) return;
+        uint32_t y = prev_slots[i];
+        if (cseg[y] < 0) { changed[y] = 1; sig[y] = 0; }
+    }
+};
+
+// this iteration's touched slots, kept for the next iteration's MarkUntouched
+struct SaveTouched {
+    int64_t cap;
+    const uint64_t* adj;
+    const uint32_t* touched;
+    const uint32_t* n_touched;
+    uint32_t* slots;
+    uint32_t* n_out;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        uint32_t k = *n_touched;
+        if (i == 0) *n_out = k;
+        if (i < (int64_t)k) slots[i] = (uint32_t)(adj[touched[i]] >> 32);
+    }
+};
+
+// end of an iteration that is followed by another: the touched slots' digests become the
+// ones to compare with, their flags and segment starts are cleared
+struct EndIteration {
+    int64_t n_adj;
+    const uint64_t* adj;
+    const uint64_t* dsig;
+    int32_t* cseg;
+    uint64_t* sig;
+    uint8_t* changed;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t x = (uint32_t)(adj[e] >> 32);
+        if (e > 0 && (uint32_t)(adj[e - 1] >> 32) == x) return;      // the slot's first entry does it
+        sig[x] = dsig[e];
+        changed[x] = 0;
+        cseg[x] = -1;
+    }
+};
+
+// end of the sweep: the flags (and, with clear_sig, the digests) of the given slots
+struct ClearChangedAdj {
+    int64_t n_adj;
+    const uint64_t* adj;
+    uint8_t* changed;
+    uint64_t* sig;
+    int32_t clear_sig;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t x = (uint32_t)(adj[e] >> 32);
+        changed[x] = 0;
+        if (clear_sig) sig[x] = 0;
+    }
+};
+struct ClearChangedList {
+    int64_t cap;
+    const uint32_t* slots;
+    const uint32_t* count;
+    uint8_t* changed;
+    uint64_t* sig;
+    int32_t clear_sig;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        if (i >= (int64_t)*count) return;
+        uint32_t x = slots[i];
+        changed[x] = 0;
+        if (clear_sig) sig[x] = 0;
+    }
+};
+
+// Re-test, against the versioned positions, every candidate pair that involves a slot whose
+// versioned positions changed since the previous iteration (SegDisplacement, MarkUntouched;
+// in the first iteration: every touched slot).  A pair of two unchanged slots keeps the
+// status the previous iteration gave it, which is its membership in the current hypothesis
+// (ContactCarry).  Elements [0, 10 n_adj): cell selector * n_adj + index into the list of
+// touched slots; elements [10 n_adj, 10 (n_adj + cap_prev)): the same over the previous
+// iteration's touched slots, of which only those no longer touched have work to do here.
+// (The nine cells of one slot are re-tested by different lanes; elements past the end of
+// a list have nothing to do.)  A pair of two changed slots is emitted once, by the lower slot.
 // Two passes around a scan, like ContactDetect: counts[t] and the first kRetestKept hits'
 // keys, then keys at offsets[t] (elements with more hits than that redo their tests).
 constexpr int kRetestKept = 4;
@@ -1310,6 +1418,10 @@ struct ContactRetest {
     const uint32_t* dmax_bits;
     const uint32_t* touched;   // the first adjacency entry of every touched slot
     const uint32_t* n_touched;
+    const uint8_t* changed;    // slot -> versioned positions differ from the previous iteration's
+    int64_t cap_prev;          // room in prev_slots
+    const uint32_t* prev_slots;
+    const uint32_t* n_prev;
     uint32_t* counts;
     const uint32_t* offsets;
     uint64_t* first_key;       // count pass: keys of an element's first kRetestKept hits, from [kRetestKept t] on
@@ -1328,17 +1440,35 @@ struct ContactRetest {
         // element = cell selector * n_adj + touched-slot number: the lanes of a wave look at the same
         // one of the nine cells for 64 consecutive touched slots, so they run loops of similar length
         // (and a wave whose cell is out of reach for all of them ends at once)
-        const uint32_t which_u = (uint32_t)t / (uint32_t)n_adj;
-        const int64_t ti = t - (int64_t)which_u * n_adj;
-        int which = (int)which_u;
+        int which;
+        uint32_t x = 0;
+        double reach_x = 0.0;
+        bool work = false;
+        if (t < 10 * n_adj) {
+            const uint32_t which_u = (uint32_t)t / (uint32_t)n_adj;
+            const int64_t ti = t - (int64_t)which_u * n_adj;
+            which = (int)which_u;
+            if (ti < (int64_t)*n_touched) {
+                const int64_t e = touched[ti];
+                x = (uint32_t)(adj[e] >> 32);
+                reach_x = dseg[e];
+                work = changed[x] != 0;
+            }
+        } else {
+            const int64_t t2 = t - 10 * n_adj;
+            const uint32_t which_u = (uint32_t)t2 / (uint32_t)cap_prev;
+            const int64_t ti = t2 - (int64_t)which_u * cap_prev;
+            which = (int)which_u;
+            if (ti < (int64_t)*n_prev) {
+                x = prev_slots[ti];
+                work = cseg[x] < 0;              // no contact any more: at its initial position throughout
+            }
+        }
         uint32_t found = 0;
-        if (ti < (int64_t)*n_touched) {
-            const int64_t e = touched[ti];
-            const uint32_t x = (uint32_t)(adj[e] >> 32);
+        if (work) {
             const CellBody bx = g.body[x];
             uint32_t px = bx.idx;
             int32_t rx = bx.r;
-            double reach_x = dseg[e];
             uint32_t at = write_pass ? offsets[t] : 0u;
             const bool skip_cell = prune && which != 0 && which != 5 &&
                 cell_beyond_reach(g, cell_size, bx, which, (double)(rx + r_max) + reach_x + double_of_float_bits(*dmax_bits));
@@ -1366,7 +1496,7 @@ struct ContactRetest {
             if (!skip_cell)
             for_each_slot_in_cell(g, x, which, [&](uint32_t y) {
                 int32_t sy = cseg[y];
-                if (sy >= 0 && y < x) return;         // two touched slots: the lower slot's pass emits the pair
+                if (y < x && changed[y]) return;      // two changed slots: the lower slot's pass emits the pair
                 const CellBody by = g.body[y];
                 int32_t ry = by.r;
                 // no version of x and y can touch if their initial positions are further
@@ -1387,14 +1517,15 @@ struct ContactRetest {
     }
 };
 
-// contacts of the initial-state sweep whose two slots are untouched by the
-// current hypothesis keep their initial status: carry them over (same two-pass
-// scheme; its counts follow the re-test's in the same array)
-struct ContactCarryClean {
+// contacts of the current hypothesis whose two slots are unchanged keep the status the
+// previous iteration gave them: carry them over (same two-pass scheme; its counts follow
+// the re-test's in the same array)
+struct ContactCarry {
     int64_t n;
-    GridView g;
-    const uint64_t* h0keys;
-    const int32_t* cseg;
+    const uint64_t* hkeys;
+    const uint32_t* hsi;
+    const uint32_t* hsj;
+    const uint8_t* changed;
     uint32_t* counts;
     const uint32_t* offsets;
     uint64_t* out_keys;
@@ -1402,21 +1533,19 @@ struct ContactCarryClean {
     PSIM_HD void operator()(int64_t h) const
     {
         if (write_pass) {
-            if (counts[h]) out_keys[offsets[h]] = h0keys[h];
+            if (counts[h]) out_keys[offsets[h]] = hkeys[h];
             return;
         }
-        uint32_t si, sj;
-        decode_pair_key(g, h0keys[h], &si, &sj);
-        counts[h] = (cseg[si] < 0 && cseg[sj] < 0) ? 1u : 0u;
+        counts[h] = (changed[hsi[h]] == 0 && changed[hsj[h]] == 0) ? 1u : 0u;
     }
 };
 
 // One launch for the three element ranges of a re-test pass: [0, nt) re-tests, [nt, nt + n0)
-// carried-over clean contacts and, in the count pass, [nt + n0, nt + n0 + nH) the contacts
-// still waiting on a predecessor.
+// carried-over contacts (n0 = size of the hypothesis) and, in the count pass,
+// [nt + n0, nt + n0 + nH) the contacts still waiting on a predecessor.
 struct RetestPass {
     ContactRetest retest;
-    ContactCarryClean carry;
+    ContactCarry carry;
     CountPending pending;
     int64_t nt, n0;
     PSIM_HD void operator()(int64_t i) const

@@ -132,6 +132,10 @@ public:
     DevBuf<uint64_t> h0[2], hc[2], hn[2], adj[2];
     DevBuf<uint32_t> hsi, hsj, done, pcount, poffs, moved_list;
     DevBuf<uint32_t> tflag, tpos, tlist;     // touched slots of the current hypothesis (flags, scan, list of first entries)
+    DevBuf<uint64_t> slot_sig, dsig;         // incremental re-test: per-slot digest of the previous iteration's versions; this iteration's
+    DevBuf<uint8_t> slot_changed;
+    bool incremental_dirty = false;
+    DevBuf<uint32_t> prev_slots[2];          // touched slots of the previous / the current iteration
     DevBuf<uint64_t> first_key;
     DevBuf<uint8_t> moved;
     DevBuf<double> cdelta;
@@ -671,6 +675,7 @@ public:
         size_t c = want + want / 4 + 1024;
         for (int i = 0; i < 2; ++i) { h0[i].ensure(c); hc[i].ensure(c); hn[i].ensure(c); adj[i].ensure(2 * c); }
         hsi.ensure(c); hsj.ensure(c); done.ensure(c); prevl.ensure(2 * c); outp.ensure(2 * c); outv.ensure(2 * c);
+        prev_slots[0].ensure(2 * c); prev_slots[1].ensure(2 * c);
         cgeo.ensure(3 * c); cvals.ensure(3 * c);
         tflag.ensure(2 * c); tpos.ensure(2 * c); tlist.ensure(2 * c);
         sum_pe.ensure(c); sum_ke.ensure(c); sum_heat.ensure(c);
@@ -810,6 +815,27 @@ public:
         uint32_t nH = n0;
         uint64_t* adjs = nullptr;
         uint32_t round = 0, last_exec = 0;
+        // Incremental re-test: per slot a digest of its versioned positions in the previous
+        // iteration (zero at the start and at the end of every sweep), a flag where this
+        // iteration's differ, and the list of the previous iteration's touched slots.
+        slot_sig.ensure_zero(ln.s, (size_t)n); slot_changed.ensure_zero(ln.s, (size_t)n);
+        if (incremental_dirty) {
+            // a sweep that ended in an error may have left digests or flags behind
+            be::dev_memset(ln.s, slot_sig.p, 0, slot_sig.cap * 8);
+            be::dev_memset(ln.s, slot_changed.p, 0, slot_changed.cap);
+        }
+        incremental_dirty = true;
+        be::dev_memset(ln.s, ctr + 9, 0, 8);
+        int prev_list = 0;                 // prev_slots[prev_list] / ctr[9 + prev_list]: the previous iteration's touched slots
+        int64_t cap_prev = 0;              // room that list needs (twice the previous hypothesis' size)
+        // end of the sweep, however it ends: every digest and flag this sweep set is cleared
+        auto wipe = [&](int64_t n_adj_now) {
+            if (adjs && n_adj_now > 0)
+                be::launch(ln.s, n_adj_now, ClearChangedAdj{n_adj_now, adjs, slot_changed.p, slot_sig.p, 1});
+            for (int i = 0; i < 2; ++i)
+                be::launch(ln.s, (int64_t)(2 * ccap), ClearChangedList{(int64_t)(2 * ccap), prev_slots[i].p, ctr + 9 + i,
+                                                                      slot_changed.p, slot_sig.p, 1});
+        };
         for (int iter = 0;; ++iter) {
             ++solver_fixpoint_iters;
             if (iter > 100000) throw std::runtime_error("psim: collision solver did not converge");
@@ -824,6 +850,7 @@ public:
             scan_scratch.ensure_zero(ln.s, be::scan_temp_words(2ull * nH));
             be::exclusive_scan_u32(ln.s, tflag.p, tpos.p, 2ull * nH, scan_scratch.p, ctr + 8, small_groups_now(ln.small_groups));
             be::launch(ln.s, 2ll * nH, CompactFirst{2ll * nH, tflag.p, tpos.p, tlist.p});
+            be::launch(ln.s, 2ll * nH, SaveTouched{2ll * nH, adjs, tlist.p, ctr + 8, prev_slots[prev_list ^ 1].p, ctr + 9 + (prev_list ^ 1)});
             // Dependency rounds.  A first batch is launched without asking how far it got (a
             // round with nothing ready is a no-op); whether contacts are still pending is read
             // back together with the re-test count below, and only then are more rounds run.
@@ -845,23 +872,32 @@ public:
             // ---- re-test what the hypothesis could have changed (count, scan, write)
             uint32_t nNew = 0;
             {
-                int64_t nt = 20ll * nH, ntot = nt + n0;
+                int64_t nt = 10ll * (2ll * nH + cap_prev), ntot = nt + nH;
                 if (nt >= (1ll << 32)) throw std::runtime_error("psim: too many contacts for one sweep");
                 pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)kRetestKept * (size_t)nt);
                 scan_scratch.ensure_zero(ln.s, be::scan_temp_words((uint64_t)ntot));
-                dseg.ensure(2 * (size_t)nH);
-                be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1});
+                dseg.ensure(2 * (size_t)nH); dsig.ensure(2 * (size_t)nH);
+                auto displacement_and_changes = [&]() {
+                    be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1,
+                                                               H, slot_sig.p, dsig.p, slot_changed.p});
+                    if (cap_prev > 0)
+                        be::launch(ln.s, cap_prev, MarkUntouched{cap_prev, prev_slots[prev_list].p, ctr + 9 + prev_list, cseg.p,
+                                                                 slot_sig.p, slot_changed.p});
+                };
+                displacement_and_changes();
                 RetestPass rp;
                 ContactRetest& r = rp.retest;
                 r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outp.p;
                 r.dseg = dseg.p;
                 r.prune = sweep == 0 ? 1 : 0; r.r_max = max_radius; r.cell_size = (double)cfg.cell_size; r.dmax_bits = ctr + 7;
                 r.touched = tlist.p; r.n_touched = ctr + 8;
+                r.changed = slot_changed.p; r.cap_prev = cap_prev > 0 ? cap_prev : 1; r.prev_slots = prev_slots[prev_list].p;
+                r.n_prev = ctr + 9 + prev_list;
                 r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
-                rp.carry = ContactCarryClean{(int64_t)n0, g, H0, cseg.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
+                rp.carry = ContactCarry{(int64_t)nH, H, hsi.p, hsj.p, slot_changed.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
                 rp.pending = CountPending{(int64_t)nH, done.p, ctr + 1, ctr + 6};
-                rp.nt = nt; rp.n0 = n0;
+                rp.nt = nt; rp.n0 = nH;
                 for (;;) {
                     be::launch(ln.s, ntot + nH, rp);
                     be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, (uint64_t)ntot, scan_scratch.p, ctr, small_groups_now(ln.small_groups));
@@ -879,11 +915,13 @@ public:
                     // versions; run further rounds and re-test again
                     if (round > 4102 + nH) throw std::runtime_error("psim: internal: contact schedule stalled");
                     run_rounds(6);
-                    be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1});
+                    displacement_and_changes();
                 }
                 if (nNew > ccap) {
                     // growing reallocates every contact buffer: restart the whole sweep
                     be::launch(ln.s, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+                    wipe(2ll * nH);
+                    incremental_dirty = false;
                     be::sync(ln.s);
                     ensure_contact_capacity(ln, nNew);
                     n_candidates -= cand;
@@ -907,13 +945,21 @@ public:
             if (same) break;
             uint64_t* kn[2] = {hn[0].p, hn[1].p};
             hn_which = be::radix_sort_pairs<uint64_t>(ln.s, kn, nullptr, nNew, 0, key_bits, ln.sort_tmp->p);
-            be::launch(ln.s, 2ll * nH, ResetSeg{2ll * nH, adjs, cseg.p});
+            // this iteration's digests become the ones the next compares with; flags and segment starts cleared
+            be::launch(ln.s, 2ll * nH, EndIteration{2ll * nH, adjs, dsig.p, cseg.p, slot_sig.p, slot_changed.p});
+            if (cap_prev > 0)
+                be::launch(ln.s, cap_prev, ClearChangedList{cap_prev, prev_slots[prev_list].p, ctr + 9 + prev_list,
+                                                            slot_changed.p, slot_sig.p, 0});
+            prev_list ^= 1;                 // (SaveTouched filled the other list with this iteration's touched slots)
+            cap_prev = 2ll * nH;
             hc[0].swap(hn[hn_which]);       // the sorted new list becomes the hypothesis (same capacity)
             H = hc[0].p;
             nH = nNew;
-            if (nH == 0) return;
+            if (nH == 0) { adjs = nullptr; wipe(0); incremental_dirty = false; return; }
         }
         // ---- settled: positions written back, list of slots touched for the first time
+        wipe(2ll * nH);
+        incremental_dirty = false;
         pcount.ensure(2 * (size_t)nH); poffs.ensure(2 * (size_t)nH);
         ContactFinalizePositions f;
         f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outp.p; f.body = cbody.p;
