@@ -60,7 +60,8 @@ typedef struct psim_config {
                                          1 = one lane per particle; 2 = wave-cooperative, one group per wave;
                                          3 / 4 = as 0 / 2 with the 64-bit element offsets the kernels switch to
                                          for trees of 4 GiB and more forced on (tests) */
-    int32_t debug;                    /* 1 = keep the per-step contact log and delta-temperature array */
+    int32_t debug;                    /* bit 0: keep the per-step contact log and delta-temperature array;
+                                         bit 1: take the contact solver's large-hypothesis path at any size (tests) */
     int32_t overlap;                  /* 1 = run the grid build and the first contact-sweep count pass on a
                                          side stream underneath the tree walk (default in the Python binding) */
 } psim_config;

@@ -1324,6 +1324,53 @@ struct MarkUntouched {
     }
 };
 
+// For large hypotheses the slots the re-test has to look at are compacted into a list first
+// (flag, scan, write), so that its launches and scans cover the changed slots only and not
+// every touched one: element i < n_adj stands for the i-th touched slot, the rest for the
+// previous iteration's touched slots.  Entry = slot << 32 | first adjacency entry (kNoEntry
+// for a slot without contacts).
+constexpr uint32_t kNoEntry = 0xffffffffu;
+struct WorkFlags {
+    int64_t n_adj, cap_prev;
+    const uint64_t* adj;
+    const uint32_t* touched;
+    const uint32_t* n_touched;
+    const uint32_t* prev_slots;
+    const uint32_t* n_prev;
+    const int32_t* cseg;
+    const uint8_t* changed;
+    uint32_t* flags;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        uint32_t f = 0;
+        if (i < n_adj) {
+            if (i < (int64_t)*n_touched) f = changed[(uint32_t)(adj[touched[i]] >> 32)] ? 1u : 0u;
+        } else if (i - n_adj < (int64_t)*n_prev) {
+            f = cseg[prev_slots[i - n_adj]] < 0 ? 1u : 0u;
+        }
+        flags[i] = f;
+    }
+};
+struct WorkList {
+    int64_t n_adj, cap_prev;
+    const uint64_t* adj;
+    const uint32_t* touched;
+    const uint32_t* prev_slots;
+    const uint32_t* flags;
+    const uint32_t* pos;
+    uint64_t* list;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        if (!flags[i]) return;
+        if (i < n_adj) {
+            uint32_t e = touched[i];
+            list[pos[i]] = (adj[e] & 0xffffffff00000000ull) | (uint64_t)e;
+        } else {
+            list[pos[i]] = ((uint64_t)prev_slots[i - n_adj] << 32) | (uint64_t)kNoEntry;
+        }
+    }
+};
+
 // this iteration's touched slots, kept for the next iteration's MarkUntouched
 struct SaveTouched {
     int64_t cap;
@@ -1422,6 +1469,8 @@ struct ContactRetest {
     int64_t cap_prev;          // room in prev_slots
     const uint32_t* prev_slots;
     const uint32_t* n_prev;
+    const uint64_t* work;      // optional: the compacted list of changed slots (WorkList); elements are then
+    int64_t n_work;            // cell selector * n_work + index into it
     uint32_t* counts;
     const uint32_t* offsets;
     uint64_t* first_key;       // count pass: keys of an element's first kRetestKept hits, from [kRetestKept t] on
@@ -1444,7 +1493,16 @@ struct ContactRetest {
         uint32_t x = 0;
         double reach_x = 0.0;
         bool work = false;
-        if (t < 10 * n_adj) {
+        if (this->work) {
+            const uint32_t which_u = (uint32_t)(t / n_work);
+            const int64_t ti = t - (int64_t)which_u * n_work;
+            which = (int)which_u;
+            const uint64_t w = this->work[ti];
+            x = (uint32_t)(w >> 32);
+            const uint32_t e = (uint32_t)w;
+            reach_x = e != kNoEntry ? dseg[e] : 0.0;
+            work = true;
+        } else if (t < 10 * n_adj) {
             const uint32_t which_u = (uint32_t)t / (uint32_t)n_adj;
             const int64_t ti = t - (int64_t)which_u * n_adj;
             which = (int)which_u;

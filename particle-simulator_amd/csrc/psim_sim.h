@@ -136,6 +136,8 @@ public:
     DevBuf<uint8_t> slot_changed;
     bool incremental_dirty = false;
     DevBuf<uint32_t> prev_slots[2];          // touched slots of the previous / the current iteration
+    DevBuf<uint32_t> wflag, wpos;            // compacted list of the changed slots (large hypotheses)
+    DevBuf<uint64_t> wlist;
     DevBuf<uint64_t> first_key;
     DevBuf<uint8_t> moved;
     DevBuf<double> cdelta;
@@ -872,10 +874,6 @@ public:
             // ---- re-test what the hypothesis could have changed (count, scan, write)
             uint32_t nNew = 0;
             {
-                int64_t nt = 10ll * (2ll * nH + cap_prev), ntot = nt + nH;
-                if (nt >= (1ll << 32)) throw std::runtime_error("psim: too many contacts for one sweep");
-                pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)kRetestKept * (size_t)nt);
-                scan_scratch.ensure_zero(ln.s, be::scan_temp_words((uint64_t)ntot));
                 dseg.ensure(2 * (size_t)nH); dsig.ensure(2 * (size_t)nH);
                 auto displacement_and_changes = [&]() {
                     be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1,
@@ -884,7 +882,35 @@ public:
                         be::launch(ln.s, cap_prev, MarkUntouched{cap_prev, prev_slots[prev_list].p, ctr + 9 + prev_list, cseg.p,
                                                                  slot_sig.p, slot_changed.p});
                 };
+                // A large hypothesis: make sure every contact has run before the (expensive) re-test
+                // is launched -- one small readback instead of a re-test thrown away.
+                const bool large = (cfg.debug & 2) || 2ll * nH + cap_prev > (1ll << 18);      // (debug bit 2: forced, for tests)
+                if (large) {
+                    for (;;) {
+                        be::dev_memset(ln.s, ctr + 1, 0, 4);
+                        be::launch(ln.s, nH, CountPending{(int64_t)nH, done.p, ctr + 1, ctr + 6});
+                        if (read_u32(ln, ctr + 1) == 0) break;
+                        if (round > 4102 + nH) throw std::runtime_error("psim: internal: contact schedule stalled");
+                        run_rounds(6);
+                    }
+                }
                 displacement_and_changes();
+                // ... and only the changed slots get elements: their compacted list
+                int64_t n_work = 0;
+                if (large) {
+                    const int64_t nw = 2ll * nH + cap_prev;
+                    wflag.ensure((size_t)nw); wpos.ensure((size_t)nw); wlist.ensure((size_t)nw);
+                    scan_scratch.ensure_zero(ln.s, be::scan_temp_words((uint64_t)nw));
+                    be::launch(ln.s, nw, WorkFlags{2ll * nH, cap_prev, adjs, tlist.p, ctr + 8, prev_slots[prev_list].p, ctr + 9 + prev_list,
+                                                   cseg.p, slot_changed.p, wflag.p});
+                    be::exclusive_scan_u32(ln.s, wflag.p, wpos.p, (uint64_t)nw, scan_scratch.p, ctr + 11, small_groups_now(ln.small_groups));
+                    be::launch(ln.s, nw, WorkList{2ll * nH, cap_prev, adjs, tlist.p, prev_slots[prev_list].p, wflag.p, wpos.p, wlist.p});
+                    n_work = read_u32(ln, ctr + 11);
+                }
+                int64_t nt = large ? 10ll * n_work : 10ll * (2ll * nH + cap_prev), ntot = nt + nH;
+                if (nt >= (1ll << 32)) throw std::runtime_error("psim: too many contacts for one sweep");
+                pcount.ensure((size_t)ntot); poffs.ensure((size_t)ntot); first_key.ensure((size_t)kRetestKept * (size_t)nt + 1);
+                scan_scratch.ensure_zero(ln.s, be::scan_temp_words((uint64_t)ntot));
                 RetestPass rp;
                 ContactRetest& r = rp.retest;
                 r.n_adj = 2ll * nH; r.g = g; r.adj = adjs; r.cseg = cseg.p; r.hkeys = H; r.hsi = hsi.p; r.out = outp.p;
@@ -893,6 +919,7 @@ public:
                 r.touched = tlist.p; r.n_touched = ctr + 8;
                 r.changed = slot_changed.p; r.cap_prev = cap_prev > 0 ? cap_prev : 1; r.prev_slots = prev_slots[prev_list].p;
                 r.n_prev = ctr + 9 + prev_list;
+                r.work = large ? wlist.p : nullptr; r.n_work = n_work > 0 ? n_work : 1;
                 r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
                 rp.carry = ContactCarry{(int64_t)nH, H, hsi.p, hsj.p, slot_changed.p, pcount.p + nt, poffs.p + nt, nullptr, 0};

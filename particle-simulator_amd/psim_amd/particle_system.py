@@ -60,7 +60,7 @@ def make_config(config, bounds, stage_mask=_capi.STAGE_ALL, walk_mode=0, debug=F
     c.solver_iterations = int(config.get('collision_solver_iterations', 1))
     c.stage_mask = int(stage_mask)
     c.walk_mode = int(walk_mode)
-    c.debug = 1 if debug else 0
+    c.debug = int(debug)        # True / 1: keep debug arrays; 3: also force the large-hypothesis re-test path (tests)
     c.overlap = 1 if overlap else 0
     return c
 

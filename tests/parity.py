@@ -96,7 +96,7 @@ def run_golden_stepwise(name, library, walk_mode=0):
 
 def run_against_oracle(n, sim, seed, bounds, steps, library, walk_mode=0, state=None, stage_mask=31,
                        check_contacts=True, oracle_threads=1, oracle_fast_pow=False, system_class=None,
-                       prime=True, min_contacts=0, min_exploded=0, log_cap=1 << 22):
+                       prime=True, min_contacts=0, min_exploded=0, log_cap=1 << 22, debug=True):
     """Same seeded inputs through this build and through the C oracle.
     oracle_threads / oracle_fast_pow only make the oracle's gravity loop affordable at
     full benchmark sizes (threads do not change its results; the rsqrt form of x**-1.5
@@ -111,7 +111,7 @@ def run_against_oracle(n, sim, seed, bounds, steps, library, walk_mode=0, state=
     o = OracleSystem(n, sim, rng_a, bounds, state=state, stage_mask=stage_mask)
     o.set_threads(oracle_threads)
     o.set_fast_pow(oracle_fast_pow)
-    s = (system_class or ParticleSystem)(n, dict(sim), rng_b, bounds, library=library, walk_mode=walk_mode, debug=True,
+    s = (system_class or ParticleSystem)(n, dict(sim), rng_b, bounds, library=library, walk_mode=walk_mode, debug=debug,
                                          state=state, stage_mask=stage_mask)
     o.enable_contact_log(log_cap)
     if prime:

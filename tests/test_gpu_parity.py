@@ -91,6 +91,16 @@ def test_dense_cluster_vs_oracle(n, sigma):
     parity.run_against_oracle(n, SIM, 1, bounds, 2, HIP, state=st, oracle_threads=_host_threads())
 
 
+def test_large_hypothesis_path_forced_vs_oracle():
+    """the contact solver's large-list path (compacted list of changed slots, pending check
+    before the re-test) forced on at sizes the small path normally takes"""
+    bounds = (4000, 4000)
+    st = parity.gaussian_cluster_state(30000, bounds, 250.0, 3)
+    parity.run_against_oracle(30000, SIM, 1, bounds, 2, HIP, state=st, oracle_threads=_host_threads(), debug=3)
+    sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)
+    parity.run_against_oracle(20000, sim, 6, (3000, 1700), 3, HIP, debug=3)
+
+
 def test_oracle_dense_hot_20k():
     """4x default density, hot start: contact chains and explosions"""
     sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)

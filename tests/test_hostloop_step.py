@@ -132,6 +132,17 @@ def test_stage_masks_vs_oracle(mask):
     parity.run_against_oracle(4000, sim, 9, (1100, 800), 3, HOSTLOOP, walk_mode=1, stage_mask=mask)
 
 
+def test_large_hypothesis_path_of_the_contact_solver_vs_oracle():
+    """the contact solver's path for large contact lists (changed slots compacted into a work
+    list, pending contacts checked before the re-test) forced on at a small size: a dense
+    Gaussian blob, many fixed-point iterations, contact pair lists bit-exact"""
+    n, bounds = 6000, (900, 900)
+    st = parity.gaussian_cluster_state(n, bounds, 90.0, 3)
+    parity.run_against_oracle(n, SIM, 1, bounds, 3, HOSTLOOP, walk_mode=1, state=st, debug=3, min_contacts=3000)
+    sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)
+    parity.run_against_oracle(2500, sim, 6, (1060, 600), 3, HOSTLOOP, walk_mode=1, debug=3)
+
+
 def test_tree_walk_against_all_pairs():
     """theta = 0 opens every node, so the walk must reproduce the all-pairs sum (to
     summation order); theta = 0.5 must stay within Barnes-Hut's approximation error"""
