@@ -162,6 +162,20 @@ struct SegmentOffsets {
     }
 };
 
+// The segments after the last key (SegmentOffsets' element k = n), one lane per segment: that
+// element would sit alone in the launch's last wave and fill them one by one (whole empty grid
+// rows below a disk of particles).
+struct SegmentOffsetsTail {
+    int64_t n;
+    const uint32_t* keys;
+    int32_t* offsets;
+    uint32_t num_segments;
+    PSIM_HD void operator()(int64_t c) const
+    {
+        if (c > (int64_t)keys[n - 1]) offsets[c] = (int32_t)n;      // c = 0 .. num_segments
+    }
+};
+
 // largest cell population without same-address atomics: WaveMaxOccupancy (over cells
 // rounded up to whole waves) stores one maximum per 64 cells, WaveMaxU32 folds such a
 // list 64-fold per launch, FinalMax (one wave) folds what is left.

@@ -439,7 +439,12 @@ public:
         if (bits < 1) bits = 1;
         sorted_ckey = be::radix_sort_pairs<uint32_t>(s, k, v, (uint64_t)n, 0, bits, tmp.p);
         offsets.ensure(cells + 1);
-        be::launch(s, n + 1, SegmentOffsets{n, ckey[sorted_ckey].p, offsets.p, (uint32_t)cells});
+        if (n > 0) {
+            be::launch(s, n, SegmentOffsets{n, ckey[sorted_ckey].p, offsets.p, (uint32_t)cells});
+            be::launch(s, (int64_t)cells + 1, SegmentOffsetsTail{n, ckey[sorted_ckey].p, offsets.p, (uint32_t)cells});
+        } else {
+            be::dev_memset(s, offsets.p, 0, (cells + 1) * sizeof(int32_t));
+        }
         cbody.ensure(c);
         be::launch(s, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pos.p, radii.p, cbody.p, cfg.grid_w});
         tree_n = n;
