@@ -204,7 +204,7 @@ public:
         if (cfg.overlap != 0 && n > 0) {
 #endif
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
-            else per_simd = (n < (8ll << 20) && !sharded_step) ? 6.5 : 6;
+            else per_simd = sharded_step ? 6 : (n < (8ll << 20) ? 6.5 : 6.25);
         }
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
