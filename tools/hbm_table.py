@@ -14,24 +14,30 @@ import re
 import sqlite3
 import sys
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = list(sys.argv[1:])
 n = 1 << 22
-if "--n" in sys.argv:
-    n = int(sys.argv[sys.argv.index("--n") + 1])
+if "--n" in args:
+    at = args.index("--n")
+    n = int(args[at + 1])
+    del args[at:at + 2]
 PEAK = 8000.0   # GB/s, MI355X HBM3E specification
 
 # kernel-name substring -> (label, algorithmic bytes per particle)
+# (bytes that every launch moves whatever the data: stores that only happen for some
+# particles -- wall hits -- are left out, so the figure is a lower bound on the traffic)
 ROWS = [
     ("DriftKeys", "DriftKeys (drift + Morton key + cell id)", 84),
     ("sort_pass_kernel<unsigned long, 16>", "Morton sort pass (u64 key + u32 index)", 24),
-    ("sort_pass_kernel<unsigned int, 16>", "cell sort pass (u32 key + u32 index)", 16),
-    ("FixRuns", "FixRuns", 24),
-    ("GatherTree", "GatherTree (random 16 B + 8 B gather)", 52),
+    ("sort_pass_kernel<unsigned int, 16>", "cell / Hilbert sort pass (u32 key + u32 index)", 16),
+    ("FixRuns", "FixRuns", 48),
+    ("GatherTree", "GatherTree (random 16 B + 8 B gather, Hilbert key)", 60),
     ("GatherCell", "GatherCell (random 16 B + 4 B gather)", 60),
-    ("TreeEmitLeaves", "TreeEmitLeaves", 0),
+    ("TreeLinks", "TreeLinks", 13),
+    ("tree_emit_tile_kernel", "tree_emit_tile_kernel (elements + in-tile centres of mass)", 97),
     ("Kick", "Kick", 64),
-    ("WallsFlag", "WallsFlag (+ conduction delta, cooling)", 60),
+    ("WallsFlag", "WallsFlag (+ conduction delta, cooling)", 61),
 ]
+ACHIEVABLE = 6300.0   # GB/s: above this the inputs were (partly) served by the 256 MiB Infinity Cache
 
 
 def last_step(db, value_sql):
@@ -61,7 +67,7 @@ def counter_of(path, name):
 fetch = counter_of(args[1] if len(args) > 1 else None, "FETCH_SIZE")
 write = counter_of(args[2] if len(args) > 2 else None, "WRITE_SIZE")
 
-print("%-44s %5s %9s %9s %7s %6s %10s %10s" % ("kernel", "calls", "us/call", "alg MB", "GB/s", "frac", "FETCH MB", "WRITE MB"))
+print("%-60s %5s %9s %9s %7s %6s %10s %10s" % ("kernel", "calls", "us/call", "alg MB", "GB/s", "frac", "FETCH MB", "WRITE MB"))
 for sub, label, bpp in ROWS:
     full = (n + 4095) // 4096 * 256 if "sort_pass" in sub else n      # launches over all n particles only
     d = [(r[2] - r[1]) / 1e3 for r in kern if sub in r[0] and full <= r[3] < full + 512]
@@ -75,6 +81,11 @@ for sub, label, bpp in ROWS:
     ws = "%10.1f" % (max(w) * 1024 / 1e6) if w else "%10s" % "-"
     if bpp:
         gbs = mb / 1e3 / (us * 1e-6)
-        print("%-44s %5d %9.1f %9.1f %7.0f %6.3f %s %s" % (label, len(d), us, mb, gbs, gbs / PEAK, fs, ws))
+        if gbs > ACHIEVABLE:
+            # not an HBM rate: inputs written by the kernels just before are still on the die
+            print("%-60s %5d %9.1f %9.1f %7.0f %6s %s %s  (inputs resident in the Infinity Cache: no HBM fraction)" % (
+                label, len(d), us, mb, gbs, "-", fs, ws))
+        else:
+            print("%-60s %5d %9.1f %9.1f %7.0f %6.3f %s %s" % (label, len(d), us, mb, gbs, gbs / PEAK, fs, ws))
     else:
-        print("%-44s %5d %9.1f %9s %7s %6s %s %s" % (label, len(d), us, "-", "-", "-", fs, ws))
+        print("%-60s %5d %9.1f %9s %7s %6s %s %s" % (label, len(d), us, "-", "-", "-", fs, ws))
