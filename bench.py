@@ -273,7 +273,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "particles": n, "theta": SIM["barnes_hut_theta"],
                        "multi_gpu": ("one simulation sharded over %d ranks: walk by sorted-target range, contact detection "
-                                     "and conduction by grid-slot slabs, RCCL all-gathers" % world) if world > 1 else "single"},
+                                     "and conduction by grid-slot slabs, RCCL all-gathers" % world) if world > 1 else
+                                     ("single (stage entry points of the sharded path, one rank)" if args.staged else "single")},
             "roofline": {"kernel": "gravity_walk_multi_kernel", "bound": "valu", "achieved": achieved,
                          "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": None,
