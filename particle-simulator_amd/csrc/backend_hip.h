@@ -436,6 +436,7 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
 constexpr int kSortItemsLong = 16, kSortItemsShort = 4;
 constexpr uint64_t kSortLongFrom = 1u << 20;
 constexpr int kMaxSortPasses = 8;
+constexpr int kLookBatch = 8;                 // predecessors a sort tile's look-back requests at once
 constexpr uint32_t kLookValue = 0x3fffffffu;
 constexpr uint32_t kLookLocal = 1u << 30;       // this tile's own count
 constexpr uint32_t kLookInclusive = 2u << 30;   // count of this tile and every tile before it
@@ -563,10 +564,27 @@ __global__ void __launch_bounds__(256) sort_pass_kernel(const KeyT* kin, const u
         bool ok = true;
         int64_t t = (int64_t)tile - 1;
         uint32_t polls = 0;
-        while (t >= 0) {
-            uint32_t v = __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t f = v >> 30;
-            if (f == 0) {
+        // kLookBatch predecessors are requested at once and then taken in order: the tiles of
+        // a launch publish their own counts at about the same time, so a tile far into the
+        // grid walks back over many of them, and one memory round trip per predecessor was
+        // most of a pass (a tile that is not there counts as "everything before it: nothing")
+        for (bool found = false; !found;) {
+            uint32_t v[kLookBatch];
+#pragma unroll
+            for (int u = 0; u < kLookBatch; ++u)
+                v[u] = (t - u >= 0) ? __hip_atomic_load(status + (size_t)(t - u) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : kLookInclusive;
+            int taken = 0;
+#pragma unroll
+            for (int u = 0; u < kLookBatch; ++u) {
+                const uint32_t f = v[u] >> 30;
+                if (found || f == 0 || taken != u) continue;
+                before += v[u] & kLookValue;
+                taken = u + 1;
+                if (f == 2) found = true;
+            }
+            t -= taken;
+            if (taken == 0) {
                 if ((++polls & 255u) == 0 &&
                     (polls >= kLookSpinLimit ||
                      __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -574,11 +592,7 @@ __global__ void __launch_bounds__(256) sort_pass_kernel(const KeyT* kin, const u
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
-                continue;
             }
-            before += v & kLookValue;
-            if (f == 2) break;
-            --t;
         }
         if (ok) {
             __hip_atomic_store(my_status, kLookInclusive | ((before + mine) & kLookValue), __ATOMIC_RELAXED,

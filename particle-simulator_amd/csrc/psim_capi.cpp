@@ -26,7 +26,6 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     uint32_t total = (uint32_t)(n + n_internal);
     double theta2 = cfg.theta * cfg.theta;          // particle_system.py:88 theta * theta * dist_sq
 #if !defined(PSIM_HOSTLOOP)
-    join_hilbert();
     if (cfg.walk_mode == 0 || cfg.walk_mode == 3) {
         // default: two walks per wave (3: with 64-bit element offsets forced, as on arrays of 4 GiB and more)
         be::launch_walk_multi<2>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
@@ -46,7 +45,7 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     }
 #endif
     GravityWalkSimple k;
-    k.n = hi - lo; k.s0 = lo; k.sorted_out = sorted_out ? 1 : 0; k.rec = rec.p; k.total_elems = total; k.spos = spos.p;
+    k.n = hi - lo; k.s0 = lo; k.sorted_out = sorted_out ? 1 : 0; k.order = walk_order(); k.rec = rec.p; k.total_elems = total; k.spos = spos.p;
     k.smass = smass.p; k.perm = perm[sorted_key].p; k.inv_mass = inv_mass.p; k.acc_out = out; k.w2tab = w2tab.p;
     k.root_tag = root_tag(); k.theta2 = theta2; k.g_const = cfg.gravity_constant; k.softening = cfg.softening; k.counters = nullptr;
     be::launch(st, hi - lo, k);
@@ -352,7 +351,6 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     double theta2 = s->cfg.theta * s->cfg.theta;
     psim::DevBuf<psim::vec2> scratch;
     scratch.ensure((size_t)tn);
-    s->join_hilbert();
 #if !defined(PSIM_HOSTLOOP)
     psim::DevBuf<unsigned long long> cnt;
     cnt.ensure(32);
@@ -374,7 +372,7 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     cnt.ensure(2);
     psim::be::dev_memset(s->st, cnt.p, 0, 8);
     psim::GravityWalkSimple k;
-    k.n = tn; k.s0 = 0; k.sorted_out = 0; k.rec = s->rec.p; k.total_elems = total; k.spos = s->spos.p; k.smass = s->smass.p;
+    k.n = tn; k.s0 = 0; k.sorted_out = 0; k.order = nullptr; k.rec = s->rec.p; k.total_elems = total; k.spos = s->spos.p; k.smass = s->smass.p;
     k.perm = s->perm[s->sorted_key].p; k.inv_mass = s->inv_mass.p; k.acc_out = scratch.p; k.w2tab = s->w2tab.p;
     k.root_tag = s->root_tag(); k.theta2 = theta2; k.g_const = s->cfg.gravity_constant; k.softening = s->cfg.softening; k.counters = cnt.p;
     psim::be::launch(s->st, tn, k);
@@ -403,7 +401,6 @@ static void time_walk_impl(psim_context* ctx, int32_t reps, double slots_per_sim
     double theta2 = s->cfg.theta * s->cfg.theta;
     psim::DevBuf<psim::vec2> scratch;
     scratch.ensure((size_t)tn);
-    s->join_hilbert();
     int64_t resident = (int64_t)(psim::be::compute_units() * 4 * slots_per_simd);
     auto once = [&]() {
         psim::be::launch_walk_multi<2>(s->st, (int64_t)0, tn, 0, (const psim::NodeRec*)s->rec.p, total,
@@ -587,6 +584,7 @@ static bool find_debug_array(psim::Sim* s, const std::string& name, DebugArray* 
     else if (name == "contact_vals") *a = {s->log_vals.p, s->log_n, 24};
     else if (name == "delta_temps") *a = {s->delta_dbg.p, s->delta_dbg.p ? n : 0, 8};
     else if (name == "exploded") *a = {nullptr, (int64_t)s->last_exploded.size(), 4};
+    else if (name == "tree_path") *a = {nullptr, 1, 4};
     else return false;
     return true;
 }
@@ -609,6 +607,10 @@ int psim_debug_fetch(psim_context* ctx, const char* name, void* dst, size_t byte
         size_t k = std::min(bytes, have);
         if (std::string(name) == "exploded") {
             if (k) memcpy(dst, ctx->sim->last_exploded.data(), k);
+        } else if (std::string(name) == "tree_path") {
+            // how the last tree's elements were made: 1 the cooperative kernels, 2 the per-element ones
+            const uint32_t path = ctx->sim->tree_cooperative ? 1u : 2u;
+            if (k) memcpy(dst, &path, k);
         } else if (k) {
             psim::be::copy_d2h(ctx->sim->st, dst, a.ptr, k);
             psim::be::sync(ctx->sim->st);

@@ -260,15 +260,13 @@ struct GatherCell {
 };
 
 // --------------------------------------------------------------- stage 3: linear quadtree
-// Position along a Hilbert curve of order 12 over a square: the order in which the walk
-// groups its targets.  Consecutive particles along the curve are always neighbours in
-// space (a Z-order run jumps across the domain wherever it crosses a coarse cell boundary),
-// so the 64 targets of a wave disagree less about which nodes to open: fewer loop trips and
-// fuller force blocks.  Only the grouping depends on it, no result does.
-PSIM_HD PSIM_FORCEINLINE uint32_t hilbert_index12(uint32_t ix, uint32_t iy)
+// Position of the point (ix, iy) of a 2^levels x 2^levels grid along the Hilbert curve of
+// that order.  Consecutive points along the curve are neighbours in space, whereas a Z-order
+// run jumps across the domain wherever it crosses a coarse cell boundary.
+PSIM_HD PSIM_FORCEINLINE uint32_t hilbert_index(uint32_t ix, uint32_t iy, int levels)
 {
     uint32_t h = 0, sw = 0, fl = 0;            // the curve's orientation so far: axes swapped / flipped
-    for (int l = 11; l >= 0; --l) {
+    for (int l = levels - 1; l >= 0; --l) {
         uint32_t bx = ((ix >> l) & 1u) ^ fl, by = ((iy >> l) & 1u) ^ fl;
         uint32_t rx = sw ? by : bx, ry = sw ? bx : by;
         h = (h << 2) | ((3u * rx) ^ ry);
@@ -285,22 +283,73 @@ struct GatherTree {
     const double* mass;
     vec2* spos;
     double* smass;
-    uint32_t* hkey;             // optional: Hilbert index of the sorted particle, and its own
-    uint32_t* hval;             // sorted position (input of the sort that orders the walk's targets)
-    double hscale;              // 4096 / side of the square the curve covers
     PSIM_HD void operator()(int64_t s) const
     {
         uint32_t p = perm[s];
-        vec2 P = pos[p];
-        spos[s] = P;
+        spos[s] = pos[p];
         smass[s] = mass[p];
-        if (hkey) {
-            double fx = P.x * hscale, fy = P.y * hscale;
-            uint32_t ix = fx > 0.0 ? (fx < 4095.0 ? (uint32_t)fx : 4095u) : 0u;     // (NaN -> 0)
-            uint32_t iy = fy > 0.0 ? (fy < 4095.0 ? (uint32_t)fy : 4095u) : 0u;
-            hkey[s] = hilbert_index12(ix, iy);
-            hval[s] = (uint32_t)s;
+    }
+};
+
+// The walk's targets in Hilbert order, without a sort: the order in which the walk groups its
+// targets, so that the 64 targets of a wave are neighbours in space and disagree less about
+// which nodes to open (fewer loop trips, fuller force blocks; only the grouping depends on
+// it, no result does).  The particles of one quadtree cell of a given depth are consecutive
+// in Morton order, and where each such cell comes along the curve does not depend on the
+// particles: `curve_pos` is a table made once per domain and depth (Sim::curve_table).  So
+// the order is: cells along the curve, each cell's particles in their Morton order.  Three
+// passes: where each cell's run starts and ends in the sorted keys; the runs' lengths filed
+// under the cells' curve positions (then scanned by the caller); every particle to its place.  `skip` (when set and nonzero: the keys are not fully
+// sorted, the caller is about to sort them again) makes all three do nothing.
+struct HilbertCellRuns {
+    int64_t n;
+    const uint64_t* key;
+    int shift;                  // 64 - 2 * levels
+    uint32_t* run_start;        // [cells], zero before
+    uint32_t* run_end;          // [cells], zero before
+    const uint32_t* skip;
+    PSIM_HD void operator()(int64_t s) const
+    {
+        if (*skip) return;
+        uint32_t c = (uint32_t)(key[s] >> shift);
+        if (s == 0) {
+            run_start[c] = 0u;
+        } else {
+            uint32_t before = (uint32_t)(key[s - 1] >> shift);
+            if (before != c) { run_start[c] = (uint32_t)s; run_end[before] = (uint32_t)s; }
         }
+        if (s == n - 1) run_end[c] = (uint32_t)n;
+    }
+};
+
+struct HilbertCellCounts {
+    int64_t cells;
+    const uint32_t* curve_pos;  // [cells]: position along the curve of the cell with this Morton path
+    const uint32_t* run_start;
+    const uint32_t* run_end;
+    uint32_t* count_on_curve;   // [cells]
+    const uint32_t* skip;
+    PSIM_HD void operator()(int64_t c) const
+    {
+        if (*skip) return;
+        count_on_curve[curve_pos[c]] = run_end[c] - run_start[c];
+    }
+};
+
+struct HilbertOrder {
+    int64_t n;
+    const uint64_t* key;
+    int shift;
+    const uint32_t* curve_pos;
+    const uint32_t* run_start;
+    const uint32_t* start_on_curve;     // exclusive scan of count_on_curve
+    uint32_t* order;                    // [n]: sorted positions of the particles, along the curve
+    const uint32_t* skip;
+    PSIM_HD void operator()(int64_t s) const
+    {
+        if (*skip) return;
+        uint32_t c = (uint32_t)(key[s] >> shift);
+        order[start_on_curve[curve_pos[c]] + ((uint32_t)s - run_start[c])] = (uint32_t)s;
     }
 };
 
@@ -654,9 +703,10 @@ PSIM_HD PSIM_FORCEINLINE double inv_cube_soft(double x)
 }
 
 struct GravityWalkSimple {
-    int64_t n;                  // number of targets (sorted particles s0 .. s0 + n - 1)
+    int64_t n;                  // number of targets: entries s0 .. s0 + n - 1 of `order`
     int64_t s0;
-    int32_t sorted_out;         // write acc_out[sorted position] instead of acc_out[particle index]
+    int32_t sorted_out;         // write acc_out[entry number] instead of acc_out[particle index]
+    const uint32_t* order;      // optional: sorted positions in the order the walks take them (null: 0, 1, 2, ...)
     const NodeRec* rec;
     uint32_t total_elems;
     const vec2* spos;
@@ -670,7 +720,7 @@ struct GravityWalkSimple {
     uint32_t* counters;         // optional [2]: visits, interactions
     PSIM_HD void operator()(int64_t i) const
     {
-        int64_t s = s0 + i;
+        int64_t s = order ? (int64_t)order[s0 + i] : s0 + i;
         double px = spos[s].x, py = spos[s].y;
         double ax = 0.0, ay = 0.0;
         uint32_t j = 0, visits = 0, inter = 0;
@@ -696,7 +746,7 @@ struct GravityWalkSimple {
         vec2 a;
         a.x = (gm * ax) * im;      // particle_system.py:25  a = F * (1/m)
         a.y = (gm * ay) * im;
-        acc_out[sorted_out ? (uint32_t)s : p] = a;
+        acc_out[sorted_out ? (uint32_t)(s0 + i) : p] = a;
         if (counters) {
             atomic_inc_u32(&counters[0], visits);
             atomic_inc_u32(&counters[1], inter);

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <vector>
 #include "psim_kernels.h"
 #if !defined(PSIM_HOSTLOOP)
@@ -97,18 +98,22 @@ public:
     DevBuf<uint32_t> perm[2];
     DevBuf<vec2> spos;
     DevBuf<double> smass;
-    // order in which the walk groups its targets: sorted positions along a Hilbert curve
-    // (hkey = curve index of each sorted particle, hord = the sorted positions, both sorted by hkey)
-    DevBuf<uint32_t> hkey[2], hord[2];
-    int sorted_h = 0;
-    bool hilbert_ready = false;     // hord[sorted_h] describes the current tree
+    // order in which the walk groups its targets: sorted positions along a Hilbert curve over
+    // the quadtree cells of depth hilbert_levels() (hruns: where each cell's run of particles
+    // starts and ends in Morton order; hcurve: run lengths by curve position, then their scan)
+    DevBuf<uint32_t> hord, hruns, hcurve, curve_pos;
+    bool hilbert_ready = false;     // hord describes the current tree
+    int curve_levels = -1;          // what curve_pos was made for
+    double curve_w = 0.0, curve_h = 0.0;
     DevBuf<int8_t> L;
     DevBuf<uint32_t> owned, base;
     DevBuf<NodeRec> rec;
     DevBuf<uint32_t> node_first, node_last, node_depth[2], node_id[2];
     DevBuf<double> pe_node;
     DevBuf<uint64_t> far_list;           // nodes the cooperative emit leaves to per-depth passes
-    DevBuf<uint32_t> far_count, emit_words;
+    DevBuf<uint32_t> far_count;
+    bool tree_cooperative = false;             // the last tree came from the cooperative kernels
+    static constexpr int kEmitWords = 16;      // counters[16..19]: the cooperative tree kernels' words
     DevBuf<int32_t> depth_off;
     DevBuf<double> w2tab;
     int32_t depth_off_host[40];
@@ -209,7 +214,7 @@ public:
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
     be::Stream st2;
-    be::Event ev_drift, ev_side, ev_walk, ev_gathered, ev_hilbert;
+    be::Event ev_drift, ev_side, ev_walk;
     bool walk_in_flight = false;       // a walk was submitted this step and has not been seen to finish
     // Scans on the side lane use small workgroups only while the walk is still holding its wave
     // slots; once it has finished the larger ones are faster (about 2x at tens of millions of items).
@@ -260,8 +265,6 @@ public:
         be::event_destroy(ev_drift);
         be::event_destroy(ev_side);
         be::event_destroy(ev_walk);
-        be::event_destroy(ev_gathered);
-        be::event_destroy(ev_hilbert);
         be::stream_destroy(st2);
     }
 
@@ -269,7 +272,7 @@ public:
     {
         be::mailbox_create(mailbox);
         be::mailbox_create(mailbox2);
-        counters.ensure(16);
+        counters.ensure(kEmitWords + 4);
         counters2.ensure(16);
         step_words.ensure(16);
         walk_ctr.ensure_zero(st, 16);
@@ -277,8 +280,6 @@ public:
         ev_drift = be::event_create();
         ev_side = be::event_create();
         ev_walk = be::event_create();
-        ev_gathered = be::event_create();
-        ev_hilbert = be::event_create();
         red_tmp.ensure(be::kReduceBlocks);
         red_out.ensure(8);
         depth_off.ensure(40);
@@ -541,6 +542,7 @@ public:
         spos.ensure(c); smass.ensure(c); L.ensure(c); owned.ensure(c); base.ensure(c);
         scan_tmp.ensure_zero(st, be::scan_temp_words(c));
         uint32_t m = 0;
+        bool emitted = false;
         const uint64_t* skey = nullptr;
         const uint32_t* sperm = nullptr;
         for (int attempt = 0;; ++attempt) {
@@ -559,6 +561,7 @@ public:
                 sorted_key = half ^ 1;
             } else {
                 // a long run of near-coincident particles was left unsorted: full LSD sort
+                be::dev_memset(st, counters.p + 4, 0, 4);      // (the kernels below look at this word)
                 uint64_t* k2[2] = {key[sorted_key].p, key[sorted_key ^ 1].p};
                 uint32_t* v2[2] = {perm[sorted_key].p, perm[sorted_key ^ 1].p};
                 int r = be::radix_sort_pairs<uint64_t>(st, k2, v2, (uint64_t)n, 0, 64, sort_tmp.p);
@@ -566,102 +569,130 @@ public:
             }
             skey = key[sorted_key].p;
             sperm = perm[sorted_key].p;
-            {
-                GatherTree gt;
-                gt.n = n; gt.perm = sperm; gt.pos = pos.p; gt.mass = mass.p; gt.spos = spos.p; gt.smass = smass.p;
-                gt.hkey = nullptr; gt.hval = nullptr; gt.hscale = 0.0;
-                if (walk_uses_order()) {
-                    for (int i = 0; i < 2; ++i) { hkey[i].ensure(c); hord[i].ensure(c); }
-                    double side = cfg.bounds_w > cfg.bounds_h ? cfg.bounds_w : cfg.bounds_h;
-                    gt.hkey = hkey[0].p; gt.hval = hord[0].p; gt.hscale = 4096.0 / side;
-                }
-                be::launch(st, n, gt);
-                hilbert_ready = false;
-                if (walk_uses_order()) {
-                    // Sorted by curve index (stable: particles sharing a curve cell keep their Z
-                    // order).  Nothing but the walk needs it, so it goes to the second stream when
-                    // there is one, submitted here so that the host's launch work is hidden behind
-                    // the kernels the main stream still has queued.  (Should this attempt's Morton
-                    // sort turn out incomplete, the next attempt submits it again behind this one.)
-                    uint32_t* hk[2] = {hkey[0].p, hkey[1].p};
-                    uint32_t* hv[2] = {hord[0].p, hord[1].p};
-                    if (cfg.overlap != 0) {
-                        sort_tmp2.ensure(be::sort_temp_words(c));
-                        be::event_record(ev_gathered, st);
-                        be::stream_wait(st2, ev_gathered);
-                        sorted_h = be::radix_sort_pairs<uint32_t>(st2, hk, hv, (uint64_t)n, 0, 24, sort_tmp2.p);
-                        be::event_record(ev_hilbert, st2);
-                    } else {
-                        sorted_h = be::radix_sort_pairs<uint32_t>(st, hk, hv, (uint64_t)n, 0, 24, sort_tmp.p);
-                    }
-                    hilbert_ready = true;
-                }
+            be::launch(st, n, GatherTree{n, sperm, pos.p, mass.p, spos.p, smass.p});
+            hilbert_ready = false;
+            if (walk_uses_order()) {
+                // cells along the curve, each cell's particles in Morton order: no sort needed
+                // (three streaming passes and a scan over the cells; they look at the word
+                // FixRuns raises and do nothing when the keys are still to be sorted again)
+                const int levels = hilbert_levels();
+                const int64_t cells = 1ll << (2 * levels);
+                const int shift = 64 - 2 * levels;
+                curve_table(levels);
+                hord.ensure(c); hruns.ensure(2 * (size_t)cells); hcurve.ensure((size_t)cells);
+                be::dev_memset(st, hruns.p, 0, 2 * (size_t)cells * 4);
+                be::launch(st, n, HilbertCellRuns{n, skey, shift, hruns.p, hruns.p + cells, counters.p + 4});
+                be::launch(st, cells, HilbertCellCounts{cells, curve_pos.p, hruns.p, hruns.p + cells, hcurve.p, counters.p + 4});
+                be::exclusive_scan_u32(st, hcurve.p, hcurve.p, (uint64_t)cells, scan_tmp.p, nullptr);
+                be::launch(st, n, HilbertOrder{n, skey, shift, curve_pos.p, hruns.p, hcurve.p, hord.p, counters.p + 4});
+                hilbert_ready = true;
             }
             be::launch(st, n, TreeLinks{n, skey, L.p, owned.p});
             be::exclusive_scan_u32(st, owned.p, base.p, (uint64_t)n, scan_tmp.p, counters.p);
-            uint32_t five[5];
-            readback(five, counters.p, 20, true);      // [0] internal nodes, [4] FixRuns overflow
-            m = five[0];
-            if (attempt == 0 && five[4] != 0) continue;
+#if !defined(PSIM_HOSTLOOP)
+            {
+                // The elements, by two cooperative kernels that read the node count from the
+                // scan's total themselves (and do nothing when the tree is unusable: the key sort
+                // incomplete, more nodes than the pool holds), so that the host reads back once,
+                // after them: elements assembled tile by tile in LDS with the centre of mass of
+                // every subtree that ends inside its tile, then the nodes that span tiles.
+                // Buffers are sized for the pool's limit (as many internal nodes as particles).
+                ensure_tree_buffers(c);
+                const uint32_t tiles = be::emit_tiles(n);
+                far_list.ensure((size_t)tiles * be::kEmitSlots); far_count.ensure(tiles);
+                uint32_t* ew = counters.p + kEmitWords;
+                be::dev_memset(st, ew, 0, 16);
+                be::TreeEmitArgs a;
+                a.n = n; a.key = skey; a.L = L.p; a.base = base.p; a.spos = spos.p; a.smass = smass.p;
+                a.counts = counters.p; a.root_tag = root_tag(); a.rec = rec.p; a.node_first = node_first.p;
+                a.node_last = node_last.p; a.far_list = far_list.p; a.far_count = far_count.p; a.words = ew;
+                be::launch_tree_emit(st, a);
+                uint32_t w[kEmitWords + 4];
+                readback(w, counters.p, sizeof(w), true);      // [0] internal nodes, [4] FixRuns overflow, then the emit words
+                m = w[0];
+                if (attempt == 0 && w[4] != 0) continue;
+                check_pool(m);
+                if (w[kEmitWords + 1] != 0) throw std::runtime_error("psim: internal: tree nodes spanning tiles did not settle");
+                emitted = w[kEmitWords + 2] == 0;
+            }
+#else
+            {
+                uint32_t five[5];
+                readback(five, counters.p, 20, true);      // [0] internal nodes, [4] FixRuns overflow
+                m = five[0];
+                if (attempt == 0 && five[4] != 0) continue;
+                check_pool(m);
+            }
+#endif
             break;
         }
-        // the reference's pool holds 4N+1 nodes = at most N subdivided cells (quadtree.py:165)
-        if ((uint64_t)m > (uint64_t)n) throw std::runtime_error("psim: quadtree node pool overflow (near-coincident particles)");
         n_internal = m;
-        size_t mm = m ? m : 1;
-        rec.ensure(c + mm);
-        node_first.ensure(mm); node_last.ensure(mm); node_depth[0].ensure(mm); node_depth[1].ensure(mm);
-        node_id[0].ensure(mm); node_id[1].ensure(mm); pe_node.ensure(mm);
-        bool emitted = false;
-#if !defined(PSIM_HOSTLOOP)
-        {
-            // one cooperative pass: elements assembled tile by tile in LDS, centres of mass of
-            // every subtree that ends inside its tile formed there, each element written once
-            const uint32_t tiles = be::emit_tiles(n);
-            far_list.ensure((size_t)tiles * be::kEmitSlots); far_count.ensure(tiles); emit_words.ensure(4);
-            be::dev_memset(st, emit_words.p, 0, 16);
-            be::TreeEmitArgs a;
-            a.n = n; a.key = skey; a.L = L.p; a.base = base.p; a.spos = spos.p; a.smass = smass.p;
-            a.total_elems = (uint32_t)(n + m); a.root_tag = root_tag(); a.rec = rec.p; a.node_first = node_first.p;
-            a.node_last = node_last.p; a.far_list = far_list.p; a.far_count = far_count.p; a.words = emit_words.p;
-            be::launch_tree_emit(st, a);
-            uint32_t w[3];
-            readback(w, emit_words.p, 12);
-            if (w[2] == 0) {
-                // what the tiles left over: the nodes whose subtree reaches beyond their tile
-                be::TreeFarRanges fr;
-                fr.count = (int64_t)tiles * be::kEmitSlots; fr.n = n; fr.far_list = far_list.p; fr.far_count = far_count.p;
-                fr.key = skey; fr.base = base.p; fr.node_first = node_first.p; fr.total_elems = (uint32_t)(n + m);
-                fr.rec = rec.p; fr.node_last = node_last.p;
-                be::launch(st, fr.count, fr);
-                be::TreeComFar f;
-                f.count = (int64_t)tiles * be::kEmitSlots; f.far_list = far_list.p; f.far_count = far_count.p;
-                f.ch = node_children(); f.rec = rec.p;
-                const int dlo = w[0] ? 64 - (int)w[0] : 0, dhi = (int)w[1];
-                for (int d = dhi - 1; d >= dlo; --d) { f.depth = (uint32_t)d; be::launch(st, f.count, f); }
-                emitted = true;
-            }
+        tree_cooperative = emitted;
+        if (!emitted) {
+            ensure_tree_buffers(m ? m : 1);
+            emit_per_element(skey, m);
         }
-#endif
-        if (!emitted) emit_per_element(skey, m);
         tree_valid = true;
     }
 
-    // the wave-cooperative walks take their targets in Hilbert order; the one-lane-per-particle
-    // walk (and the test-only host-loop build, which has no other) in sorted order
-    bool walk_uses_order() const
+    // the reference's pool holds 4N+1 nodes = at most N subdivided cells (quadtree.py:165)
+    void check_pool(uint32_t m) const
     {
-#if defined(PSIM_HOSTLOOP)
-        return false;
-#else
-        return cfg.walk_mode != 1;
-#endif
+        if ((uint64_t)m > (uint64_t)n) throw std::runtime_error("psim: quadtree node pool overflow (near-coincident particles)");
     }
-    const uint32_t* walk_order() const { return hilbert_ready ? hord[sorted_h].p : nullptr; }
-    // the main stream may use walk_order() after this
-    void join_hilbert()
+    void ensure_tree_buffers(size_t mm)
     {
-        if (hilbert_ready && cfg.overlap != 0) be::stream_wait(st, ev_hilbert);
+        rec.ensure((size_t)n + mm);
+        node_first.ensure(mm); node_last.ensure(mm); node_depth[0].ensure(mm); node_depth[1].ensure(mm);
+        node_id[0].ensure(mm); node_id[1].ensure(mm); pe_node.ensure(mm);
+    }
+
+    // the walks take their targets in Hilbert order (every walk kernel accepts it; the
+    // one-lane-per-particle walk gains nothing from it and is given it all the same, so that
+    // the test-only host-loop build, which has no other walk, covers the ordering kernels)
+    bool walk_uses_order() const { return true; }
+    const uint32_t* walk_order() const { return hilbert_ready ? hord.p : nullptr; }
+    // curve_pos[c]: where the quadtree cell with Morton path c (depth `levels`) comes when the
+    // cells are put in the order of their centres along a fine Hilbert curve over the square
+    // that bounds the domain.  (The quadtree's cells have the domain's aspect, 2:1 by default;
+    // a curve over the cell grid itself would string such cells into long thin groups.)  Made
+    // on the host whenever the depth or the domain changes: a particle count that crosses a
+    // power of four, in practice once.
+    void curve_table(int levels)
+    {
+        if (levels == curve_levels && cfg.bounds_w == curve_w && cfg.bounds_h == curve_h) return;
+        const uint32_t cells = 1u << (2 * levels);
+        const double side = cfg.bounds_w > cfg.bounds_h ? cfg.bounds_w : cfg.bounds_h;
+        const double fx = cfg.bounds_w / side * 65536.0 / (double)(1u << levels);
+        const double fy = cfg.bounds_h / side * 65536.0 / (double)(1u << levels);
+        std::vector<uint64_t> by_curve(cells);
+        for (uint32_t c = 0; c < cells; ++c) {
+            uint32_t ix = 0, iy = 0;
+            for (int l = levels - 1; l >= 0; --l) {
+                uint32_t q = (c >> (2 * l)) & 3u;        // morton_key: y bit above x bit
+                ix = (ix << 1) | (q & 1u);
+                iy = (iy << 1) | (q >> 1);
+            }
+            uint32_t px = (uint32_t)(((double)ix + 0.5) * fx), py = (uint32_t)(((double)iy + 0.5) * fy);
+            if (px > 65535u) px = 65535u;
+            if (py > 65535u) py = 65535u;
+            by_curve[c] = ((uint64_t)hilbert_index(px, py, 16) << 32) | c;
+        }
+        std::sort(by_curve.begin(), by_curve.end());
+        std::vector<uint32_t> table(cells);
+        for (uint32_t r = 0; r < cells; ++r) table[(uint32_t)by_curve[r]] = r;
+        curve_pos.ensure(cells);
+        be::sync(st);
+        be::copy_h2d(st, curve_pos.p, table.data(), (size_t)cells * 4);
+        be::sync(st);
+        curve_levels = levels; curve_w = cfg.bounds_w; curve_h = cfg.bounds_h;
+    }
+    // depth of the cells the curve runs over: about 4 particles per cell (inside a cell the order
+    // is Morton's; 16 per cell cost 2.5 % more walk trips at 4 Mi particles)
+    int hilbert_levels() const
+    {
+        int levels = (ceil_log2_u64((uint64_t)n) - 2 + 1) / 2;
+        return levels < 1 ? 1 : (levels > 11 ? 11 : levels);
     }
 
     NodeChildren node_children() const

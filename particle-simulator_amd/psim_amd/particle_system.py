@@ -382,7 +382,7 @@ class ParticleSystem:
         "node_first": (np.uint32, ()), "node_last": (np.uint32, ()), "node_depth": (np.uint32, ()),
         "depth_offsets": (np.int32, ()), "grid_offsets": (np.int32, ()), "grid_indices": (np.int32, ()),
         "cell_key": (np.uint32, ()), "contact_ij": (np.int32, (2,)), "contact_vals": (np.float64, (3,)),
-        "delta_temps": (np.float64, ()), "exploded": (np.int32, ()),
+        "delta_temps": (np.float64, ()), "exploded": (np.int32, ()), "tree_path": (np.uint32, ()),
     }
 
     def debug_array(self, name):

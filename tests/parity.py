@@ -215,6 +215,51 @@ def clustered_state(n, bounds, seed, clusters, per, spread):
     return dict(positions=pos[perm], masses=masses[perm], temperatures=temps[perm])
 
 
+def tight_pairs_state(n, bounds, seed, pairs, gap, box):
+    """uniform particles plus `pairs` couples `gap` px apart, all couples inside one square of
+    `box` px: consecutive in Morton order, each couple owning a chain of a dozen or more
+    internal nodes (one per level between the depth that isolates the couple and the depth
+    that parts it), so a few hundred consecutive particles own thousands of nodes"""
+    rng = np.random.default_rng(seed)
+    b = np.array(bounds, dtype=np.float64)
+    pos = rng.random((n, 2)) * b
+    corner = b * 0.37
+    for k in range(pairs):
+        a = corner + rng.random(2) * box
+        pos[2 * k] = a
+        pos[2 * k + 1] = a + gap * (0.5 + rng.random(2))
+    perm = rng.permutation(n)
+    return dict(positions=pos[perm], masses=rng.uniform(5.0, 20.0, (n, 1))[perm],
+                temperatures=rng.uniform(0.05, 0.1, (n, 1))[perm])
+
+
+def check_tree_against_oracle(library, state, n, bounds, expect_path=None):
+    """whole tree (topology, masses, centres of mass: bit-exact) and the accelerations of one
+    state against the oracle.  expect_path: 1 = the elements must have come from the
+    cooperative kernels, 2 = from the per-element ones (the HIP library reports which)."""
+    from oracle.oracle import OracleSystem
+    sim = dict(particle_count=n, min_mass=5.0, max_mass=20.0, gravity_constant=0.01, softening_factor=10,
+               barnes_hut_theta=0.5, min_temp=0.05, max_temp=0.1, heat_transfer_coefficient=0.1,
+               coefficient_of_restitution=0.5, grid_cell_size_multiplier=10.0, position_correction_factor=1.05,
+               collision_solver_iterations=1, explosion_efficiency=0.5, thermal_damping_factor=0.0005)
+    o = OracleSystem(n, sim, np.random.default_rng(0), bounds, state=state)
+    s = ParticleSystem(n, dict(sim), np.random.default_rng(0), bounds, library=library, state=state, debug=True)
+    o._calculate_gravity()
+    s._calculate_gravity()
+    if expect_path is not None:
+        assert int(s.debug_array("tree_path")[0]) == expect_path
+    want, got = o.canonical_tree(), s.canonical_tree()
+    assert got["tree_nodes"] == want["tree_nodes"]
+    for k in TREE_KEYS_EXACT + TREE_KEYS_COM:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    acc_close(s.accelerations, o.accelerations)
+    s.update()
+    o.update()
+    assert s.counts()["tree_nodes"] == o.num_active_nodes
+    acc_close(s.accelerations, o.accelerations)
+    s.close()
+
+
 def out_of_bounds_state(n, bounds, seed, outside):
     """dense uniform particles, `outside` of them moved up to 30 px beyond the four edges
     (walls only act at the end of a step, so a drifted particle can sit outside

@@ -201,3 +201,25 @@ def test_render_feed_and_pair_potential():
 
 def test_exactly_coincident_particles_form_a_bucket():
     parity.check_exactly_coincident_particles(HIP)
+
+
+def test_whole_tree_from_the_cooperative_kernels_vs_oracle():
+    # 391 tiles; hundreds of nodes span tiles, up to the root
+    n, bounds = 100003, (3000.0, 2000.0)
+    st = dict(positions=np.random.default_rng(5).random((n, 2)) * np.array(bounds),
+              masses=np.random.default_rng(6).uniform(5.0, 20.0, (n, 1)),
+              temperatures=np.full((n, 1), 0.07))
+    parity.check_tree_against_oracle(HIP, st, n, bounds, expect_path=1)
+
+
+def test_tile_with_too_many_nodes_takes_the_per_element_kernels():
+    n, bounds = 8000, (2000.0, 1000.0)
+    st = parity.tight_pairs_state(n, bounds, 3, pairs=160, gap=1e-4, box=20.0)
+    parity.check_tree_against_oracle(HIP, st, n, bounds, expect_path=2)
+
+
+def test_deep_chains_across_tiles_vs_oracle():
+    # couples spread over the whole domain: deep chains, few per tile, the cooperative path
+    n, bounds = 30000, (2000.0, 1000.0)
+    st = parity.tight_pairs_state(n, bounds, 4, pairs=60, gap=1e-3, box=900.0)
+    parity.check_tree_against_oracle(HIP, st, n, bounds, expect_path=1)

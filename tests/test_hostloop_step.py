@@ -158,3 +158,9 @@ def test_tree_walk_against_all_pairs():
 
 def test_exactly_coincident_particles_form_a_bucket():
     parity.check_exactly_coincident_particles(HOSTLOOP)
+
+
+def test_tight_pairs_tree_vs_oracle():
+    n, bounds = 8000, (2000.0, 1000.0)
+    st = parity.tight_pairs_state(n, bounds, 3, pairs=160, gap=1e-4, box=20.0)
+    parity.check_tree_against_oracle(HOSTLOOP, st, n, bounds, expect_path=2)
