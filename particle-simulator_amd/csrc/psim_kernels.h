@@ -1187,15 +1187,34 @@ struct ContactSimulate {
         int32_t pi = prev[2 * h], pj = prev[2 * h + 1];
         if (pi >= 0) { uint32_t d = done[pi]; if (d == 0 || d == round) return; }
         if (pj >= 0) { uint32_t d = done[pj]; if (d == 0 || d == round) return; }
+        run(h, pi, pj);
+        done[h] = round;
+    }
+    // contact h itself, its predecessors' outputs being in place (done[h] is the caller's to set)
+    PSIM_HD void run(int64_t h, int32_t pi, int32_t pj) const
+    {
         uint32_t si = hsi[h], sj = hsj[h];
         vec2 I = fetch(si, pi), J = fetch(sj, pj);
+        apply(h, prepare(h, si, sj), I, J);
+    }
+    // the same in pieces, for a caller that holds the predecessors' outputs itself: what the
+    // contact needs besides the two states, a slot's state before any contact, the contact
+    typedef vec2 State;
+    struct Pre { double mi, mj; int32_t ri, rj; };
+    PSIM_HD Pre prepare(int64_t, uint32_t si, uint32_t sj) const
+    {
+        Pre p;
+        p.mi = mass[body[si].idx]; p.mj = mass[body[sj].idx]; p.ri = body[si].r; p.rj = body[sj].r;
+        return p;
+    }
+    PSIM_HD State initial(uint32_t slot) const { return body_pos(body[slot]); }
+    PSIM_HD void apply(int64_t h, const Pre& p, State& I, State& J) const
+    {
         double v[3];
-        resolve_pair_positions(I, J, mass[body[si].idx], mass[body[sj].idx], body[si].r, body[sj].r, G, soft,
-                               pos_correct, v);
+        resolve_pair_positions(I, J, p.mi, p.mj, p.ri, p.rj, G, soft, pos_correct, v);
         out[2 * h] = I;
         out[2 * h + 1] = J;
         geo[3 * h] = v[0]; geo[3 * h + 1] = v[1]; geo[3 * h + 2] = v[2];
-        done[h] = round;
     }
 };
 
@@ -1233,10 +1252,29 @@ struct ContactVelocity {
     PSIM_HD void operator()(int64_t h) const
     {
         if (done[h] != round) return;
+        run(h, prev[2 * h], prev[2 * h + 1]);
+    }
+    PSIM_HD void run(int64_t h, int32_t pi, int32_t pj) const
+    {
         uint32_t si = hsi[h], sj = hsj[h];
-        VelState I = fetch(si, prev[2 * h]), J = fetch(sj, prev[2 * h + 1]);
+        VelState I = fetch(si, pi), J = fetch(sj, pj);
+        apply(h, prepare(h, si, sj), I, J);
+    }
+    // (in pieces, as in ContactSimulate)
+    typedef VelState State;
+    struct Pre { double mi, mj, g[3]; };
+    PSIM_HD Pre prepare(int64_t h, uint32_t si, uint32_t sj) const
+    {
+        Pre p;
+        p.mi = mass[body[si].idx]; p.mj = mass[body[sj].idx];
+        p.g[0] = geo[3 * h]; p.g[1] = geo[3 * h + 1]; p.g[2] = geo[3 * h + 2];
+        return p;
+    }
+    PSIM_HD State initial(uint32_t slot) const { return fetch(slot, -1); }
+    PSIM_HD void apply(int64_t h, const Pre& p, State& I, State& J) const
+    {
         double v[3];
-        resolve_pair_velocities(I, J, mass[body[si].idx], mass[body[sj].idx], geo + 3 * h, restitution, v);
+        resolve_pair_velocities(I, J, p.mi, p.mj, p.g, restitution, v);
         out[2 * h] = I;
         out[2 * h + 1] = J;
         vals[3 * h] = v[0]; vals[3 * h + 1] = v[1]; vals[3 * h + 2] = v[2];

@@ -12,6 +12,7 @@
 #include "psim_kernels.h"
 #if !defined(PSIM_HOSTLOOP)
 #include "psim_tree_hip.h"
+#include "psim_contact_hip.h"
 #endif
 
 namespace psim {
@@ -136,6 +137,7 @@ public:
     size_t ccap = 0;
     DevBuf<uint64_t> h0[2], hc[2], hn[2], adj[2];
     DevBuf<uint32_t> hsi, hsj, done, pcount, poffs, moved_list;
+    DevBuf<uint32_t> round_tiles;             // per tile of 1024 contacts: left, first label, last label (cooperative rounds)
     DevBuf<uint32_t> tflag, tpos, tlist;     // touched slots of the current hypothesis (flags, scan, list of first entries)
     DevBuf<uint64_t> slot_sig, dsig;         // incremental re-test: per-slot digest of the previous iteration's versions; this iteration's
     DevBuf<uint8_t> slot_changed;
@@ -712,6 +714,7 @@ public:
         if (want <= ccap) return;
         size_t c = want + want / 4 + 1024;
         for (int i = 0; i < 2; ++i) { h0[i].ensure(c); hc[i].ensure(c); hn[i].ensure(c); adj[i].ensure(2 * c); }
+        round_tiles.ensure(3 * (c / 1024 + 1));
         hsi.ensure(c); hsj.ensure(c); done.ensure(c); prevl.ensure(2 * c); outp.ensure(2 * c); outv.ensure(2 * c);
         prev_slots[0].ensure(2 * c); prev_slots[1].ensure(2 * c);
         cgeo.ensure(3 * c); cvals.ensure(3 * c);
@@ -900,7 +903,12 @@ public:
                     sm.n = nH; sm.hsi = hsi.p; sm.hsj = hsj.p; sm.prev = prevl.p; sm.done = done.p; sm.round = round;
                     sm.out = outp.p; sm.geo = cgeo.p; sm.body = cbody.p;
                     sm.mass = mass.p; sm.G = cfg.gravity_constant; sm.soft = cfg.softening; sm.pos_correct = cfg.pos_correct;
+#if defined(PSIM_HOSTLOOP)
                     be::launch(ln.s, nH, sm);
+#else
+                    // (a launch carries the chains inside each tile of contacts as far as they go)
+                    be::launch_contact_rounds<true>(ln.s, sm, nH, prevl.p, done.p, round, round_tile_view());
+#endif
                 }
                 solver_rounds += count;
             };
@@ -1036,6 +1044,14 @@ public:
     }
 
     // velocity half of the sweep whose position half ran last (main stream)
+#if !defined(PSIM_HOSTLOOP)
+    be::RoundTiles round_tile_view() const
+    {
+        const size_t t = round_tiles.cap / 3;
+        return be::RoundTiles{round_tiles.p, round_tiles.p + t, round_tiles.p + 2 * t};
+    }
+#endif
+
     void sweep_velocities(int sweep)
     {
         const uint32_t nH = settled_contacts;
@@ -1045,7 +1061,11 @@ public:
             v.n = nH; v.hsi = hsi.p; v.hsj = hsj.p; v.prev = prevl.p; v.done = done.p; v.round = r; v.out = outv.p;
             v.geo = cgeo.p; v.vals = cvals.p; v.body = cbody.p; v.vel = vel.p; v.temp = temp.p; v.mass = mass.p;
             v.restitution = cfg.restitution;
+#if defined(PSIM_HOSTLOOP)
             be::launch(st, nH, v);
+#else
+            be::launch_contact_rounds<false>(st, v, nH, prevl.p, done.p, r, round_tile_view());
+#endif
         }
         // ---- totals, log, write-back
         size_t log_cap = 0;
