@@ -188,30 +188,26 @@ public:
     // whole walk.  What runs there is latency-bound and slows down by about the share of slots
     // it is denied, while the walk slows down less than its share (4 Mi, walk alone: 3.90 / 4.08 /
     // 4.38 / 4.86 ms at 8 / 7 / 6 / 5 slots).  With collisions on, the grid build and the whole
-    // position half of the collision stage run underneath 6.5 of 8 slots below 8 Mi particles
-    // (26 walk waves per CU; 4 Mi: step 5.91 / 5.79 / 5.77 / 6.23 ms at 6 / 6.5 / 6.75 / 7 -- past
-    // the optimum the side work no longer ends with the walk) and underneath 6 from there on
-    // (16 Mi: 16.9 ms at 5.5 and at 6, 17.7 at 6.5, 18.1 with 7 and the position half after
-    // the walk).  Without collisions only the grid build is there: 7 slots from 8 Mi
+    // position half of the collision stage run underneath 6.25 of 8 slots (25 walk waves per CU).
+    // 4 Mi: step 5.18 / 5.18 / 5.20 / 5.52 ms at 6 / 6.25 / 6.5 / 6.75; 16 Mi: 14.78 / 14.81 /
+    // 14.94 / 15.41 -- flat up to the point where the side work no longer ends with the walk,
+    // then steeply worse.  Without collisions only the grid build is there: 7 slots from 8 Mi
     // particles on, the whole grid below.  Two free slots per SIMD are also what the exchange
     // kernels of a sharded step need (workgroups of up to 512 lanes).
-    // (-DPSIM_WALK_SLOTS=<per SIMD> fixes the count at build time, for kernel experiments.)
     bool sharded_step = false;     // the step in progress is driven through the stage_* calls
     bool positions_under_walk() const
     {
         return cfg.overlap != 0;
     }
+    // (Shifting slots from the walk to the side stream when the side work is the longer of the
+    // two -- dense or clumped states -- was tried with a controller fed by the measured wait:
+    // the step did not change; what one stream gains the other loses.)
     int64_t walk_resident_waves() const
     {
         double per_simd = 0;
-#if defined(PSIM_WALK_SLOTS)
-        per_simd = PSIM_WALK_SLOTS;
-        if (false) {
-#else
         if (cfg.overlap != 0 && n > 0) {
-#endif
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
-            else per_simd = sharded_step ? 6 : (n < (8ll << 20) ? 6.5 : 6.25);
+            else per_simd = sharded_step ? 6 : 6.25;
         }
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
