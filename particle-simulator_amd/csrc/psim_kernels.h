@@ -107,6 +107,9 @@ struct DriftKeys {
     double W, H, cell_size;
     int32_t gw, gh;
     int32_t do_drift;
+    const double* mass;
+    const int32_t* radii;
+    PackedBody* pack;           // the gathers' source (see PackedBody)
     PSIM_HD void operator()(int64_t i) const
     {
         vec2 p = pos[i];
@@ -116,6 +119,9 @@ struct DriftKeys {
             p.y = p.y + (v.y + 0.5 * a.y);
             pos[i] = p;
         }
+        PackedBody b;
+        b.x = p.x; b.y = p.y; b.m = mass[i]; b.r = radii[i]; b.unused = 0u;
+        pack[i] = b;
         key[i] = morton_key(p.x, p.y, W, H);
         perm[i] = (uint32_t)i;
         int32_t cx = cell_coord(p.x, cell_size, gw);
@@ -243,17 +249,16 @@ struct GatherCell {
     int64_t n;
     const uint32_t* cperm;
     const uint32_t* ckey;
-    const vec2* pos;
-    const int32_t* radii;
+    const PackedBody* pack;
     CellBody* body;
     int32_t gw;
     PSIM_HD void operator()(int64_t k) const
     {
         uint32_t p = cperm[k];
-        vec2 P = pos[p];
+        PackedBody P = pack[p];
         CellBody b;
         uint32_t c = ckey[k];
-        b.x = P.x; b.y = P.y; b.r = radii[p]; b.idx = p; b.cell = c;
+        b.x = P.x; b.y = P.y; b.r = P.r; b.idx = p; b.cell = c;
         b.cxy = (c % (uint32_t)gw) | ((c / (uint32_t)gw) << 16);
         body[k] = b;
     }
@@ -279,15 +284,16 @@ PSIM_HD PSIM_FORCEINLINE uint32_t hilbert_index(uint32_t ix, uint32_t iy, int le
 struct GatherTree {
     int64_t n;
     const uint32_t* perm;
-    const vec2* pos;
-    const double* mass;
+    const PackedBody* pack;
     vec2* spos;
     double* smass;
     PSIM_HD void operator()(int64_t s) const
     {
-        uint32_t p = perm[s];
-        spos[s] = pos[p];
-        smass[s] = mass[p];
+        PackedBody P = pack[perm[s]];
+        vec2 q;
+        q.x = P.x; q.y = P.y;
+        spos[s] = q;
+        smass[s] = P.m;
     }
 };
 

@@ -99,6 +99,7 @@ public:
     DevBuf<uint32_t> perm[2];
     DevBuf<vec2> spos;
     DevBuf<double> smass;
+    DevBuf<PackedBody> pack;       // index space: what the gathers read (written by DriftKeys)
     // order in which the walk groups its targets: sorted positions along a Hilbert curve over
     // the quadtree cells of depth hilbert_levels() (hruns: where each cell's run of particles
     // starts and ends in Morton order; hcurve: run lengths by curve position, then their scan)
@@ -112,7 +113,8 @@ public:
     DevBuf<uint32_t> node_first, node_last, node_depth[2], node_id[2];
     DevBuf<double> pe_node;
     DevBuf<uint64_t> far_list;           // nodes the cooperative emit leaves to per-depth passes
-    DevBuf<uint32_t> far_count;
+    DevBuf<uint32_t> far_count, far_offs;
+    DevBuf<uint64_t> far_nodes;
     bool tree_cooperative = false;             // the last tree came from the cooperative kernels
     static constexpr int kEmitWords = 16;      // counters[16..19]: the cooperative tree kernels' words
     DevBuf<int32_t> depth_off;
@@ -422,6 +424,8 @@ public:
         k.key = key[0].p; k.perm = perm[0].p; k.ckey = ckey[0].p; k.cperm = cperm[0].p;
         k.W = cfg.bounds_w; k.H = cfg.bounds_h; k.cell_size = (double)cfg.cell_size;
         k.gw = cfg.grid_w; k.gh = cfg.grid_h; k.do_drift = drift ? 1 : 0;
+        pack.ensure(c);
+        k.mass = mass.p; k.radii = radii.p; k.pack = pack.p;
         be::launch(st, n, k);
     }
 
@@ -445,7 +449,7 @@ public:
             be::dev_memset(s, offsets.p, 0, (cells + 1) * sizeof(int32_t));
         }
         cbody.ensure(c);
-        be::launch(s, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pos.p, radii.p, cbody.p, cfg.grid_w});
+        be::launch(s, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pack.p, cbody.p, cfg.grid_w});
         tree_n = n;
     }
 
@@ -567,7 +571,7 @@ public:
             }
             skey = key[sorted_key].p;
             sperm = perm[sorted_key].p;
-            be::launch(st, n, GatherTree{n, sperm, pos.p, mass.p, spos.p, smass.p});
+            be::launch(st, n, GatherTree{n, sperm, pack.p, spos.p, smass.p});
             hilbert_ready = false;
             if (walk_uses_order()) {
                 // cells along the curve, each cell's particles in Morton order: no sort needed
@@ -598,13 +602,15 @@ public:
                 ensure_tree_buffers(c);
                 const uint32_t tiles = be::emit_tiles(n);
                 far_list.ensure((size_t)tiles * be::kEmitSlots); far_count.ensure(tiles);
+                far_nodes.ensure((size_t)tiles * be::kEmitSlots); far_offs.ensure(tiles);
                 uint32_t* ew = counters.p + kEmitWords;
                 be::dev_memset(st, ew, 0, 16);
                 be::TreeEmitArgs a;
                 a.n = n; a.key = skey; a.L = L.p; a.base = base.p; a.spos = spos.p; a.smass = smass.p;
                 a.counts = counters.p; a.root_tag = root_tag(); a.rec = rec.p; a.node_first = node_first.p;
                 a.node_last = node_last.p; a.far_list = far_list.p; a.far_count = far_count.p; a.words = ew;
-                be::launch_tree_emit(st, a);
+                a.far_offs = far_offs.p; a.far_nodes = far_nodes.p;
+                be::launch_tree_emit(st, a, scan_tmp.p);
                 uint32_t w[kEmitWords + 4];
                 readback(w, counters.p, sizeof(w), true);      // [0] internal nodes, [4] FixRuns overflow, then the emit words
                 m = w[0];

@@ -26,7 +26,6 @@ namespace be {
 constexpr int kEmitTile = 256;          // sorted particles per workgroup, one per lane
 constexpr int kEmitCap = 704;           // elements assembled in LDS (22 KiB)
 constexpr int kEmitSlots = 32;          // nodes a tile can leave over (one per depth)
-constexpr int kFarTiles = 8;            // tiles per workgroup of tree_far_kernel (one lane per tile and slot)
 
 // what a left-over node's record holds until tree_far_kernel has settled it; each 64-bit word
 // of a record is published on its own, so each has a value of its own that says "not yet"
@@ -48,7 +47,10 @@ struct TreeEmitArgs {
     uint32_t* node_last;
     uint64_t* far_list;        // [tiles * kEmitSlots]  depth << 32 | node id
     uint32_t* far_count;       // [tiles]
-    uint32_t* words;           // zero before the launch.  [1] set by tree_far_kernel when it gave up waiting,
+    uint32_t* far_offs;        // [tiles]   exclusive scan of far_count (made between the two kernels)
+    uint64_t* far_nodes;       // [tiles * kEmitSlots]  the lists of all tiles, packed in tile order
+    uint32_t* words;           // zero before the launch.  [0] number of left-over nodes (the scan's total),
+                               // [1] set by tree_far_kernel when it gave up waiting,
                                // [2] set when the caller has to fall back to the per-element kernels: a tile
                                // ran out of room, or a node of the deepest level exists (its children are
                                // buckets of coinciding particles, which the tiles do not handle),
@@ -207,38 +209,56 @@ __global__ void __launch_bounds__(kEmitTile) tree_emit_tile_kernel(TreeEmitArgs 
     for (uint32_t i = tid; i < quads; i += kEmitTile) dst[i] = src[i];
 }
 
-// The nodes the tiles left over, all of them in one launch.  Lane = (tile, slot); a workgroup
-// covers kFarTiles consecutive tiles, and workgroups take their tiles from the END of the
-// array in the order they start (ticket counter).  A left-over node of tile t is an ancestor
-// of tile t+1's first particle that begins in tile t, so its children are: subtrees that end
-// inside tile t (finished by tree_emit_tile_kernel), left-over nodes of tile t one level down
-// (another lane of the same wave), and nodes owned by particles of later tiles (finished by
-// the emit kernel or left over there: a workgroup that started earlier).  Nobody waits for a
-// workgroup that has not started, and a lane that finds a child unsettled simply tries again
-// on the wave's next turn, so lanes of one wave never block one another.
+// The tiles' lists packed into one, in tile order: lane = (tile, slot).  An entry keeps its
+// tile: depth << 58 | tile << 32 | node id.
+struct TreeFarPack {
+    int64_t count;             // tiles * kEmitSlots
+    TreeEmitArgs a;
+    __device__ void operator()(int64_t t) const
+    {
+        if (!emit_inputs_ok(a) || a.words[2] != 0u) return;
+        const uint32_t tile = (uint32_t)(t / kEmitSlots), slot = (uint32_t)(t % kEmitSlots);
+        if (slot >= a.far_count[tile]) return;
+        const uint64_t e = a.far_list[t];
+        a.far_nodes[a.far_offs[tile] + slot] = ((e >> 32) << 58) | ((uint64_t)tile << 32) | (e & 0xffffffffull);
+    }
+};
+
+// The nodes the tiles left over, all of them in one launch, one lane per node.  Workgroups
+// take chunks of 256 nodes from the END of the packed list, in the order of a ticket counter,
+// until the list is used up.  A left-over node of tile t is an ancestor of tile t+1's first
+// particle that begins in tile t, so its children are: subtrees that end inside tile t
+// (finished by tree_emit_tile_kernel), left-over nodes of tile t one level down, and nodes
+// owned by particles of later tiles (finished by the emit kernel or left over there).  What a
+// node waits for therefore lies later in the list: in its own chunk or in a chunk whose
+// ticket was drawn earlier, by a workgroup that is running.  A lane that finds a child
+// unsettled simply tries again on the wave's next turn, so lanes never block one another.
 //
 // Records travel between workgroups through memory: every 64-bit word of a left-over node's
 // record is written and read with device-scope atomic accesses (which bypass the per-XCD L2
 // caches), and each word has its own "not yet" value, so no ordering between the words is
 // needed.  Sums are formed in child order with TreeCom's arithmetic (quadtree.py:102-114).
-__global__ void __launch_bounds__(kFarTiles * kEmitSlots) tree_far_kernel(TreeEmitArgs a, uint32_t tiles)
+__global__ void __launch_bounds__(256) tree_far_kernel(TreeEmitArgs a)
 {
     __shared__ uint32_t s_ticket;
     if (!emit_inputs_ok(a) || a.words[2] != 0u) return;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.words[3], 1u);
-    __syncthreads();
     const uint32_t n = (uint32_t)a.n;
     const uint32_t total_elems = n + a.counts[0];
-    const uint32_t back = s_ticket * (uint32_t)kFarTiles + threadIdx.x / (uint32_t)kEmitSlots;      // tiles counted from the end
-    const uint32_t slot = threadIdx.x % (uint32_t)kEmitSlots;
+    const uint32_t far_total = a.words[0];
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(a.rec);      // four per record: mass, x, y, skip | tag << 32
+  for (;;) {
+    __syncthreads();               // (everyone has read the previous ticket)
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&a.words[3], 1u);
+    __syncthreads();
+    const uint64_t back = (uint64_t)s_ticket * 256u + threadIdx.x;           // nodes counted from the end of the list
+    if ((uint64_t)s_ticket * 256u >= far_total) return;
     bool done = true;
     uint32_t at = 0, end = 0;
-    unsigned long long* words = reinterpret_cast<unsigned long long*>(a.rec);      // four per record: mass, x, y, skip | tag << 32
-    if (back < tiles) {
-        const uint32_t tile = tiles - 1u - back;
-        if (slot < a.far_count[tile]) {
-            const uint64_t entry = a.far_list[(size_t)tile * kEmitSlots + slot];
-            const int d = (int)(entry >> 32);
+    if (back < far_total) {
+        {
+            const uint64_t entry = a.far_nodes[far_total - 1u - (uint32_t)back];
+            const int d = (int)(entry >> 58);
+            const uint32_t tile = (uint32_t)(entry >> 32) & 0x3ffffffu;
             const uint32_t id = (uint32_t)entry;
             const uint32_t s = a.node_first[id];
             // Where the cell ends: the last particle whose key starts with the cell's path; it
@@ -348,17 +368,26 @@ __global__ void __launch_bounds__(kFarTiles * kEmitSlots) tree_far_kernel(TreeEm
         }
         __builtin_amdgcn_s_sleep(1);
     }
+    if (__hip_atomic_load(&a.words[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;      // (gave up: no point in going on)
+  }
 }
 
 inline uint32_t emit_tiles(int64_t n) { return (uint32_t)((n + kEmitTile - 1) / kEmitTile); }
 
-inline void launch_tree_emit(Stream st, const TreeEmitArgs& a)
+// scan_temp: scratch of exclusive_scan_u32 for `tiles` items (zero, and left zero)
+inline void launch_tree_emit(Stream st, const TreeEmitArgs& a, uint32_t* scan_temp)
 {
     if (a.n <= 0) return;
     const uint32_t tiles = emit_tiles(a.n);
     hipLaunchKernelGGL(tree_emit_tile_kernel, dim3(tiles), dim3(kEmitTile), 0, st, a);
     PSIM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(tree_far_kernel, dim3((tiles + kFarTiles - 1) / kFarTiles), dim3(kFarTiles * kEmitSlots), 0, st, a, tiles);
+    // the tiles' left-over nodes packed into one list, then settled by workgroups that keep
+    // drawing chunks of it (as many workgroups as can be resident, or fewer for a short list)
+    exclusive_scan_u32(st, a.far_count, a.far_offs, (uint64_t)tiles, scan_temp, a.words + 0);
+    launch(st, (int64_t)tiles * kEmitSlots, TreeFarPack{(int64_t)tiles * kEmitSlots, a});
+    const uint64_t chunks = ((uint64_t)tiles * kEmitSlots + 255u) / 256u;
+    const uint32_t groups = (uint32_t)(chunks < 2048u ? chunks : 2048u);
+    hipLaunchKernelGGL(tree_far_kernel, dim3(groups), dim3(256), 0, st, a);
     PSIM_HIP(hipGetLastError());
 }
 

@@ -65,6 +65,17 @@ enum StageBits : int32_t {
     kStageAll = 31,
 };
 
+// What the two gathers of a step (into Morton order for the tree, into cell order for the
+// grid) need of a particle, in one 32-byte record: they read at random particle indices, and
+// the memory system moves at least 64 bytes per access however little is asked for, so
+// position (16 B) and mass or radius (8 / 4 B) from separate arrays cost two such accesses
+// per particle and this record one.  Written by DriftKeys.
+struct alignas(32) PackedBody {
+    double x, y, m;
+    int32_t r;
+    uint32_t unused;
+};
+
 // per-contact, per-side record of the collision solver's velocity pass
 struct alignas(32) VelState {
     vec2 vel;
