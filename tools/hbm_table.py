@@ -26,12 +26,14 @@ PEAK = 8000.0   # GB/s, MI355X HBM3E specification
 # (bytes that every launch moves whatever the data: stores that only happen for some
 # particles -- wall hits -- are left out, so the figure is a lower bound on the traffic)
 ROWS = [
-    ("DriftKeys", "DriftKeys (drift + Morton key + cell id)", 84),
+    ("DriftKeys", "DriftKeys (drift + Morton key + cell id + packed record)", 128),
     ("sort_pass_kernel<unsigned long, 16>", "Morton sort pass (u64 key + u32 index)", 24),
-    ("sort_pass_kernel<unsigned int, 16>", "cell / Hilbert sort pass (u32 key + u32 index)", 16),
-    ("FixRuns", "FixRuns", 48),
-    ("GatherTree", "GatherTree (random 16 B + 8 B gather, Hilbert key)", 60),
-    ("GatherCell", "GatherCell (random 16 B + 4 B gather)", 60),
+    ("sort_pass_kernel<unsigned int, 16>", "cell sort pass (u32 key + u32 index)", 16),
+    ("FixRuns", "FixRuns", 24),
+    ("GatherTree", "GatherTree (random 32 B gather)", 60),
+    ("GatherCell", "GatherCell (random 32 B gather)", 72),
+    ("HilbertCellRuns", "HilbertCellRuns", 8),
+    ("HilbertOrder", "HilbertOrder", 12),
     ("TreeLinks", "TreeLinks", 13),
     ("tree_emit_tile_kernel", "tree_emit_tile_kernel (elements + in-tile centres of mass)", 97),
     ("Kick", "Kick", 64),
