@@ -167,10 +167,16 @@ inline void delay(Stream st, uint32_t microseconds)
 }
 
 // ------------------------------------------------------------------ launch
+// One lane per element, one wave per workgroup.  Workgroups of a single wave fit into whatever
+// wave slots are free: under the walk, which holds 26 of a CU's 32 slots, a 256-lane workgroup
+// needs four free slots at once and leaves the other two idle, and the side stream's kernels
+// ran 1.75 times slower for it (16 Mi: its wait at the end of the walk 0.40 -> 0.18 ms).  No
+// functor launched this way uses LDS or a barrier; wave-level operations are all they share.
+constexpr int kLaunchLanes = 64;
 template <class F>
-__global__ void __launch_bounds__(256) psim_kernel(int64_t n, F f)
+__global__ void __launch_bounds__(kLaunchLanes) psim_kernel(int64_t n, F f)
 {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * kLaunchLanes + threadIdx.x;
     if (i < n) f(i);
 }
 
@@ -178,9 +184,9 @@ template <class F>
 inline void launch(Stream st, int64_t n, const F& f)
 {
     if (n <= 0) return;
-    int64_t blocks = (n + 255) / 256;
+    int64_t blocks = (n + kLaunchLanes - 1) / kLaunchLanes;
     if (blocks > 0x7fffffffLL) throw std::runtime_error("launch: grid too large");
-    hipLaunchKernelGGL(psim_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, st, n, f);
+    hipLaunchKernelGGL(psim_kernel<F>, dim3((unsigned)blocks), dim3(kLaunchLanes), 0, st, n, f);
     PSIM_HIP(hipGetLastError());
 }
 

@@ -190,9 +190,9 @@ public:
     // whole walk.  What runs there is latency-bound and slows down by about the share of slots
     // it is denied, while the walk slows down less than its share (4 Mi, walk alone: 3.90 / 4.08 /
     // 4.38 / 4.86 ms at 8 / 7 / 6 / 5 slots).  With collisions on, the grid build and the whole
-    // position half of the collision stage run underneath 6.25 of 8 slots (25 walk waves per CU).
-    // 4 Mi: step 5.18 / 5.18 / 5.20 / 5.52 ms at 6 / 6.25 / 6.5 / 6.75; 16 Mi: 14.78 / 14.81 /
-    // 14.94 / 15.41 -- flat up to the point where the side work no longer ends with the walk,
+    // position half of the collision stage run underneath 6.5 of 8 slots (26 walk waves per CU).
+    // 4 Mi: step 5.04 / 4.97 / 4.96 / 5.38 ms at 6.25 / 6.5 / 6.75 / 7; 16 Mi: 14.02 / 13.86 /
+    // 13.86 / 14.98 -- flat up to the point where the side work no longer ends with the walk,
     // then steeply worse.  Without collisions only the grid build is there: 7 slots from 8 Mi
     // particles on, the whole grid below.  Two free slots per SIMD are also what the exchange
     // kernels of a sharded step need (workgroups of up to 512 lanes).
@@ -209,7 +209,7 @@ public:
         double per_simd = 0;
         if (cfg.overlap != 0 && n > 0) {
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
-            else per_simd = sharded_step ? 6 : 6.25;
+            else per_simd = sharded_step ? 6 : 6.5;
         }
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
