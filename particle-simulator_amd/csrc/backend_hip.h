@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(kScanThreads) scan_lookback_kernel(const uint3
 }
 
 // whole scan in one workgroup (n <= kScanSmall), tile after tile with a running total
-constexpr uint32_t kScanSmall = 4u * kScanTileSmall;
+constexpr uint32_t kScanSmall = 2u * kScanTileSmall;
 template <int kScanThreads>
 __global__ void __launch_bounds__(kScanThreads) scan_small_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
                                                                   uint32_t* total_out)

@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(256) tree_far_kernel(TreeEmitArgs a)
     double cm[4] = {0.0, 0.0, 0.0, 0.0}, cx[4] = {0.0, 0.0, 0.0, 0.0}, cy[4] = {0.0, 0.0, 0.0, 0.0};
     int known = done ? 0 : 1;           // children whose index is known
     int have = 0;                       // bit q: child q's record has been taken
+    int asked = 0;                      // bit q: child q has been looked at and was not settled
     bool last_known = false;            // the last child's index is among the known ones
     for (uint32_t turn = 0;; ++turn) {
         if (!done) {
@@ -316,8 +317,21 @@ __global__ void __launch_bounds__(256) tree_far_kernel(TreeEmitArgs a)
             for (int q = 0; q < 4; ++q) {
                 if (q < known && !((have >> q) & 1)) {
                     const unsigned long long* c = words + 4 * (size_t)ck[q];
+                    // A child seen unsettled before is watched through its mass word alone (the
+                    // last one its owner writes) until that changes: tens of thousands of lanes
+                    // wait at once, and four words per turn from each of them is what the
+                    // memory system then spends its time on.
+                    if (!((asked >> q) & 1)) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[q][j] = __hip_atomic_load(c + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int j = 0; j < 4; ++j) w[q][j] = __hip_atomic_load(c + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        w[q][0] = __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w[q][1] = kPendingCoord; w[q][2] = kPendingCoord; w[q][3] = 0ull;
+                        if (w[q][0] != kPendingMass) {
+#pragma unroll
+                            for (int j = 1; j < 4; ++j) w[q][j] = __hip_atomic_load(c + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
                 }
             }
             const int known_now = known;
@@ -337,6 +351,8 @@ __global__ void __launch_bounds__(256) tree_far_kernel(TreeEmitArgs a)
                             cx[q] = __longlong_as_double((long long)w[q][1]);
                             cy[q] = __longlong_as_double((long long)w[q][2]);
                             have |= 1 << q;
+                        } else {
+                            asked |= 1 << q;
                         }
                     }
                 }
