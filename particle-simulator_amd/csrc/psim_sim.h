@@ -214,14 +214,17 @@ public:
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
     be::Stream st2;
-    be::Event ev_drift, ev_side, ev_walk;
+    be::Event ev_side;
+    // (the tree's end and the walk's end are the stage timer's marks 3 and 4)
+    be::Event ev_release() { return timer.event(3); }
+    be::Event ev_walk() { return timer.event(4); }
     bool walk_in_flight = false;       // a walk was submitted this step and has not been seen to finish
     // Scans on the side lane use small workgroups only while the walk is still holding its wave
     // slots; once it has finished the larger ones are faster (about 2x at tens of millions of items).
     bool small_groups_now(bool lane_small)
     {
         if (!lane_small || !walk_in_flight) return false;
-        if (be::event_done(ev_walk)) { walk_in_flight = false; return false; }
+        if (be::event_done(ev_walk())) { walk_in_flight = false; return false; }
         return true;
     }
     // A lane = a stream with the scratch its sorts, scans and small readbacks use.  The
@@ -262,9 +265,7 @@ public:
         be::mailbox_destroy(mailbox);
         be::mailbox_destroy(mailbox2);
         be::host_free_pinned(ex_stage);
-        be::event_destroy(ev_drift);
         be::event_destroy(ev_side);
-        be::event_destroy(ev_walk);
         be::stream_destroy(st2);
     }
 
@@ -277,9 +278,7 @@ public:
         step_words.ensure(16);
         walk_ctr.ensure_zero(st, 16);
         st2 = be::stream_create();
-        ev_drift = be::event_create();
         ev_side = be::event_create();
-        ev_walk = be::event_create();
         red_tmp.ensure(be::kReduceBlocks);
         red_out.ensure(8);
         depth_off.ensure(40);
@@ -1310,14 +1309,13 @@ public:
     // (FP64-bound) and not with the tree build (memory-bound like themselves).  Joined by
     // join_side_work().
     bool side_running = false;
-    // mark_side_release() is called where the side work may start (tree built), then the walk
-    // and the kick are launched, and only then is the side work submitted: its launches would
+    // The side work may start where the tree is built (timer mark 3); the walk and the kick are
+    // launched first, and only then is the side work submitted: its launches would
     // otherwise sit between the tree build and the walk on the host's submission path, and
     // the position half waits for small readbacks.
-    void mark_side_release() { be::event_record(ev_drift, st); }
     void start_side_work()
     {
-        be::stream_wait(st2, ev_drift);
+        be::stream_wait(st2, ev_release());
         // (lets the walk, released by the same event, take its wave slots first.  Releasing the
         // side work earlier instead -- in front of the tree's last kernel, which is all latency --
         // was measured: whatever side kernel is running when the walk arrives keeps the walk's
@@ -1346,7 +1344,13 @@ public:
     }
     void join_side_work()
     {
-        if (side_running) be::stream_wait(st, ev_side);
+        if (side_running) {
+            // The host has nothing to submit before the walk ends.  If the side work ends first
+            // (the usual case) the main stream needs no wait packet for it, which otherwise
+            // sits between the kick and the velocity half for some 25 us.
+            while (walk_in_flight && !be::event_done(ev_side) && !be::event_done(ev_walk())) {}
+            if (!be::event_done(ev_side)) be::stream_wait(st, ev_side);
+        }
         side_running = false;
     }
     void begin_step()
@@ -1378,15 +1382,13 @@ public:
         // drifted positions: they run on a side stream underneath the FP64-bound walk and
         // are joined before the velocity half.
         const bool side = cfg.overlap != 0 && n > 0;
-        if (!side) build_grid();
-        timer.mark(st, 2);
+        if (!side) { build_grid(); timer.mark(st, 2); }
+        else timer.same_as(2, 1);
         build_tree();
-        timer.mark(st, 3);
-        if (side) mark_side_release();
+        timer.mark(st, 3);             // (tree built: also what releases the side stream)
         gravity(acc2.p);
-        be::event_record(ev_walk, st);
+        timer.mark(st, 4);             // (also the walk's end, as the host and the side lane ask for it)
         walk_in_flight = true;
-        timer.mark(st, 4);
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
         if (side) start_side_work();
@@ -1417,8 +1419,8 @@ public:
         keys_and_drift(true);
         timer.mark(st, 1);
         const bool side = cfg.overlap != 0 && n > 0;
-        if (!side) build_grid();
-        timer.mark(st, 2);
+        if (!side) { build_grid(); timer.mark(st, 2); }
+        else timer.same_as(2, 1);
         build_tree();
         timer.mark(st, 3);
     }
@@ -1426,11 +1428,10 @@ public:
     {
         if (lo < 0 || hi > n || lo > hi) throw std::invalid_argument("psim: bad sorted range");
         const bool side = cfg.overlap != 0 && n > 0;
-        if (side) mark_side_release();
+        // (mark 3, recorded when stage_build finished the tree, releases the side stream)
         gravity_range(lo, hi, acc_sorted, true);
-        be::event_record(ev_walk, st);
-        walk_in_flight = true;
         timer.mark(st, 4);
+        walk_in_flight = true;
         if (side) start_side_work();
     }
     // Optional, between stage_gravity and stage_kick_collide: the position half of the
