@@ -1,4 +1,4 @@
-# Round-2 measurement set, written under gpurun_out/r2prof (copied into profiles/ afterwards).
+# The measurement set kept under profiles/ (written under gpurun_out/r2prof and copied from there).
 # usage (on the GPU box): bash tools/collect_profiles.sh
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2prof
