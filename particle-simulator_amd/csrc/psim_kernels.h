@@ -365,6 +365,9 @@ struct HilbertOrder {
 // ranking on the full key (ties keep input order, like the stable radix passes).  A
 // run longer than kMaxFixRun is copied as is and reported, and the caller completes
 // the sort with the remaining radix passes.
+// (Doing the gather into sorted order in this pass as well -- whoever places a particle index
+// fetches that particle's record -- was measured: 164 us against 46 + 94 for the two kernels,
+// the lanes that finish a run fetch serially while the others of the run idle.)
 constexpr uint32_t kMaxFixRun = 48;
 struct FixRuns {
     int64_t n;
