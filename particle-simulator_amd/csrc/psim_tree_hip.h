@@ -88,6 +88,11 @@ __global__ void __launch_bounds__(kEmitTile) tree_emit_tile_kernel(TreeEmitArgs 
     }
     const bool more = s1 < n;
     const uint64_t key_next = more ? a.key[s1] : 0ull;          // first particle of the next tile
+    // (the leaf's own data, asked for now so that it is there when the leaf is assembled)
+    double leaf_m = 0.0;
+    vec2 leaf_p;
+    leaf_p.x = 0.0; leaf_p.y = 0.0;
+    if (live) { leaf_m = a.smass[s]; leaf_p = a.spos[s]; }
     __syncthreads();
     const uint32_t e0 = s0 + s_base[0];
     const uint32_t e1 = more ? s1 + s_base[s1 - s0] : total_elems;
@@ -163,9 +168,9 @@ __global__ void __launch_bounds__(kEmitTile) tree_emit_tile_kernel(TreeEmitArgs 
         if (lmax) { atomicMin(&s_dmin, lmin); atomicMax(&s_dmax, lmax); }
         const uint32_t le = s + b + (uint32_t)own;
         NodeRec r;
-        r.mass = a.smass[s];
-        r.x = a.spos[s].x;
-        r.y = a.spos[s].y;
+        r.mass = leaf_m;
+        r.x = leaf_p.x;
+        r.y = leaf_p.y;
         r.skip = le + 1;
         r.tag = kLeafTag;
         tile[le - e0] = r;
