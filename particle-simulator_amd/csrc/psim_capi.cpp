@@ -584,7 +584,7 @@ static bool find_debug_array(psim::Sim* s, const std::string& name, DebugArray* 
     else if (name == "contact_vals") *a = {s->log_vals.p, s->log_n, 24};
     else if (name == "delta_temps") *a = {s->delta_dbg.p, s->delta_dbg.p ? n : 0, 8};
     else if (name == "exploded") *a = {nullptr, (int64_t)s->last_exploded.size(), 4};
-    else if (name == "tree_path") *a = {nullptr, 1, 4};
+    else if (name == "tree_path") *a = {nullptr, 2, 4};
     else return false;
     return true;
 }
@@ -609,8 +609,9 @@ int psim_debug_fetch(psim_context* ctx, const char* name, void* dst, size_t byte
             if (k) memcpy(dst, ctx->sim->last_exploded.data(), k);
         } else if (std::string(name) == "tree_path") {
             // how the last tree's elements were made: 1 the cooperative kernels, 2 the per-element ones
-            const uint32_t path = ctx->sim->tree_cooperative ? 1u : 2u;
-            if (k) memcpy(dst, &path, k);
+            // (and how many nodes spanning tiles the cooperative kernels settled separately)
+            const uint32_t path[2] = {ctx->sim->tree_cooperative ? 1u : 2u, ctx->sim->tree_far_nodes};
+            if (k) memcpy(dst, path, k);
         } else if (k) {
             psim::be::copy_d2h(ctx->sim->st, dst, a.ptr, k);
             psim::be::sync(ctx->sim->st);

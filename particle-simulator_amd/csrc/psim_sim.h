@@ -116,6 +116,7 @@ public:
     DevBuf<uint32_t> far_count, far_offs;
     DevBuf<uint64_t> far_nodes;
     bool tree_cooperative = false;             // the last tree came from the cooperative kernels
+    uint32_t tree_far_nodes = 0;               // ... which left this many nodes (spanning tiles) to tree_far_kernel
     static constexpr int kEmitWords = 16;      // counters[16..19]: the cooperative tree kernels' words
     DevBuf<int32_t> depth_off;
     DevBuf<double> w2tab;
@@ -617,6 +618,7 @@ public:
                 check_pool(m);
                 if (w[kEmitWords + 1] != 0) throw std::runtime_error("psim: internal: tree nodes spanning tiles did not settle");
                 emitted = w[kEmitWords + 2] == 0;
+                tree_far_nodes = emitted ? w[kEmitWords + 0] : 0u;
             }
 #else
             {
