@@ -172,11 +172,18 @@ inline void delay(Stream st, uint32_t microseconds)
 // needs four free slots at once and leaves the other two idle, and the side stream's kernels
 // ran 1.75 times slower for it (16 Mi: its wait at the end of the walk 0.40 -> 0.18 ms).  No
 // functor launched this way uses LDS or a barrier; wave-level operations are all they share.
-constexpr int kLaunchLanes = 64;
-template <class F>
-__global__ void __launch_bounds__(kLaunchLanes) psim_kernel(int64_t n, F f)
+// With the device to itself a launch of millions of lanes is dispatched faster in workgroups
+// of four waves (7 M lanes: 260 against 140 us for the short kernels of the contact solver),
+// so the caller says which situation it is in: wide_groups() = no walk in flight.
+inline bool& wide_groups()
 {
-    int64_t i = (int64_t)blockIdx.x * kLaunchLanes + threadIdx.x;
+    static thread_local bool wide = false;
+    return wide;
+}
+template <class F, int LANES>
+__global__ void __launch_bounds__(LANES) psim_kernel(int64_t n, F f)
+{
+    int64_t i = (int64_t)blockIdx.x * LANES + threadIdx.x;
     if (i < n) f(i);
 }
 
@@ -184,9 +191,11 @@ template <class F>
 inline void launch(Stream st, int64_t n, const F& f)
 {
     if (n <= 0) return;
-    int64_t blocks = (n + kLaunchLanes - 1) / kLaunchLanes;
+    const int lanes = wide_groups() ? 256 : 64;
+    int64_t blocks = (n + lanes - 1) / lanes;
     if (blocks > 0x7fffffffLL) throw std::runtime_error("launch: grid too large");
-    hipLaunchKernelGGL(psim_kernel<F>, dim3((unsigned)blocks), dim3(kLaunchLanes), 0, st, n, f);
+    if (lanes == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(psim_kernel<F, 256>), dim3((unsigned)blocks), dim3(256), 0, st, n, f);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(psim_kernel<F, 64>), dim3((unsigned)blocks), dim3(64), 0, st, n, f);
     PSIM_HIP(hipGetLastError());
 }
 

@@ -224,9 +224,15 @@ public:
     // slots; once it has finished the larger ones are faster (about 2x at tens of millions of items).
     bool small_groups_now(bool lane_small)
     {
-        if (!lane_small || !walk_in_flight) return false;
-        if (be::event_done(ev_walk())) { walk_in_flight = false; return false; }
-        return true;
+        refresh_groups();
+        return lane_small && walk_in_flight;
+    }
+    // Has the walk finished?  The one-lane-per-element kernels are launched one wave per
+    // workgroup while it runs and four waves per workgroup when the device is free.
+    void refresh_groups()
+    {
+        if (walk_in_flight && be::event_done(ev_walk())) walk_in_flight = false;
+        be::wide_groups() = !walk_in_flight;
     }
     // A lane = a stream with the scratch its sorts, scans and small readbacks use.  The
     // position half of the collision stage runs on the side lane underneath the walk.
@@ -882,6 +888,7 @@ public:
         };
         for (int iter = 0;; ++iter) {
             ++solver_fixpoint_iters;
+            refresh_groups();
             if (iter > 100000) throw std::runtime_error("psim: collision solver did not converge");
             // ---- execute the hypothesis in order
             be::launch(ln.s, nH, ContactDecode{(int64_t)nH, g, H, hsi.p, hsj.p, adj[0].p, done.p});
@@ -1354,6 +1361,7 @@ public:
             if (!be::event_done(ev_side)) be::stream_wait(st, ev_side);
         }
         side_running = false;
+        refresh_groups();
     }
     void begin_step()
     {
@@ -1366,6 +1374,7 @@ public:
         totals_pending = false;
         walk_in_flight = false;
         detect_prune = true;
+        be::wide_groups() = true;
     }
     void no_collisions()
     {
@@ -1390,8 +1399,9 @@ public:
         timer.mark(st, 3);             // (tree built: also what releases the side stream)
         gravity(acc2.p);
         timer.mark(st, 4);             // (also the walk's end, as the host and the side lane ask for it)
+        be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});      // (runs when the walk has ended)
         walk_in_flight = true;
-        be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
+        be::wide_groups() = false;
         acc.swap(acc2);
         if (side) start_side_work();
         settle_positions();
@@ -1434,6 +1444,7 @@ public:
         gravity_range(lo, hi, acc_sorted, true);
         timer.mark(st, 4);
         walk_in_flight = true;
+        be::wide_groups() = false;
         if (side) start_side_work();
     }
     // Optional, between stage_gravity and stage_kick_collide: the position half of the

@@ -48,6 +48,12 @@ inline void mailbox_fetch(Stream, Mailbox&, void* dst, const void* a, uint32_t n
     if (nb) memcpy((char*)dst + (size_t)na * 4, b, (size_t)nb * 4);
 }
 
+inline bool& wide_groups()
+{
+    static bool wide = false;
+    return wide;
+}
+
 template <class F>
 inline void launch(Stream, int64_t n, const F& f)
 {
