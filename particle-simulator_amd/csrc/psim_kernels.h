@@ -1901,6 +1901,15 @@ struct Conduction {
     }
 };
 
+// plain copy of 64-bit words as a kernel of this library.  (The runtime's own device-to-device
+// copy, queued on the side stream while the walk holds most wave slots, took 5 ms for 2 MB.)
+struct CopyWords {
+    int64_t n;
+    const uint64_t* src;
+    uint64_t* dst;
+    PSIM_HD void operator()(int64_t i) const { dst[i] = src[i]; }
+};
+
 // results of a sharded stage, gathered in sorted / slot order, back to index order
 struct ScatterSorted {
     int64_t n;

@@ -825,7 +825,7 @@ public:
             key_bits = pair_key_bits();
             if (n0 > 0) {
                 ensure_contact_capacity(ln, n0);
-                be::copy_d2d(ln.s, h0[0].p, ext_keys, (size_t)n0 * 8);
+                be::launch(ln.s, n0, CopyWords{(int64_t)n0, ext_keys, h0[0].p});
             }
             ext_given = false;
             predetected = false;
