@@ -1087,9 +1087,9 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
             double4_t rv[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) rv[k] = scalar_load32_issue(rec4, j[k] << 5);
-            if (K == 2) scalar_loads_wait(rv[0], rv[1]);
-            if (K == 3) scalar_loads_wait(rv[0], rv[1], rv[2]);
-            if (K == 4) scalar_loads_wait(rv[0], rv[1], rv[2], rv[K - 1]);
+            if constexpr (K == 2) scalar_loads_wait(rv[0], rv[1]);
+            if constexpr (K == 3) scalar_loads_wait(rv[0], rv[1], rv[2]);
+            if constexpr (K == 4) scalar_loads_wait(rv[0], rv[1], rv[2], rv[3]);
 #pragma unroll
             for (int k = 0; k < K; ++k) j[k] = trip(rv[k], j[k], px[k], py[k], ax[k], ay[k], until[k]);
         }
