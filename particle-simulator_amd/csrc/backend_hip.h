@@ -3,6 +3,7 @@
 // sort, exclusive scan, ordered f64 reduction.  64-lane wavefronts throughout.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string.h>
 #include <math.h>
 #include <stdexcept>
@@ -239,12 +240,15 @@ constexpr uint32_t kLookSpinLimit = 1u << 26;   // polls before a waiting lane g
 inline uint32_t* lookback_fault_word()
 {
     static uint32_t* words[64] = {};
+    static std::mutex guard;           // (contexts may be created and used from several host threads)
     int dev = 0;
     PSIM_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) throw std::runtime_error("lookback_fault_word: device index out of range");
+    std::lock_guard<std::mutex> lock(guard);
     if (!words[dev]) {
-        words[dev] = (uint32_t*)dev_alloc(64);
-        PSIM_HIP(hipMemset(words[dev], 0, 64));
+        uint32_t* w = (uint32_t*)dev_alloc(64);
+        PSIM_HIP(hipMemset(w, 0, 64));
+        words[dev] = w;
     }
     return words[dev];
 }
