@@ -989,6 +989,117 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     }
 }
 
+// The two-group loop of gravity_walk_multi_kernel, scheduled by hand.  Same arithmetic in the
+// same order as the compiler's version of `trip` (results are bit-identical); what differs is
+// the scalar side.  Per group and trip the compiler's loop spends a third vector compare and
+// some eight scalar instructions on turning wave masks into booleans and back (is the element a
+// leaf, does any lane still want its children, has either cursor run out); every instruction
+// of a wave, scalar or vector, takes an issue turn of its SIMD, and the walk is bound by those
+// turns.  Here: the lanes that still want an element's children are the active ones that did not
+// accept, `active & ~take`, which is one s_andn2 whose SCC selects the next cursor directly;
+// a leaf needs no case of its own there (its skip is the next element, so both candidates are
+// equal); and the loop ends on an SCC branch.
+// Elements live in s[40:47] (group A) and s[48:55] (group B): {mass, x, y, skip, tag}.
+// v_rsq_f64 is followed by an independent instruction before its result is read, as the
+// compiler's schedule has it.  EXEC is all lanes on entry and is put back after each force block.
+#define PSIM_WALK_GROUP(M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                         \
+    "v_add_f64 %[dy], " Y ", -%[" PY "]\n"                                                              \
+    "v_add_f64 %[dx], " X ", -%[" PX "]\n"                                                              \
+    "s_max_u32 %[jb], " SKIP ", %[ja]\n"                                                                \
+    "v_mul_f64 %[d2], %[dy], %[dy]\n"                                                                   \
+    "s_cmp_lg_u32 " TAG ", 0\n"                                                                         \
+    "s_cselect_b32 " SKIP ", %[w2lo], 0\n"                                                              \
+    "v_fmac_f64 %[d2], %[dx], %[dx]\n"                                                                  \
+    "v_cmp_ge_u32 vcc, %[" CUR "], %[" UNTIL "]\n"                                                      \
+    "v_cmp_lt_f64 %[take], " LHS ", %[d2]\n"                                                            \
+    "s_and_b64 %[take], vcc, %[take]\n"                                                                 \
+    "s_cbranch_scc0 .Lpsim_walk_" L "%=\n"                                                              \
+    "s_mov_b64 exec, %[take]\n"                                                                         \
+    "v_add_f64 %[d2], %[soft], %[d2]\n"                                                                 \
+    "v_rsq_f64 %[y], %[d2]\n"                                                                           \
+    "v_mov_b32 %[" UNTIL "], %[jb]\n"                                                                   \
+    "v_mul_f64 %[y2], %[y], %[y]\n"                                                                     \
+    "v_mul_f64 %[y], " M ", %[y]\n"                                                                     \
+    "v_fma_f64 %[d2], -%[d2], %[y2], 1.0\n"                                                             \
+    "v_mul_f64 %[y], %[y], %[y2]\n"                                                                     \
+    "v_fma_f64 %[d2], %[d2], %[c15], 1.0\n"                                                             \
+    "v_mul_f64 %[d2], %[y], %[d2]\n"                                                                    \
+    "v_fmac_f64 %[" AX "], %[d2], %[dx]\n"                                                              \
+    "v_fmac_f64 %[" AY "], %[d2], %[dy]\n"                                                              \
+    "s_mov_b64 exec, %[sv]\n"                                                                           \
+    ".Lpsim_walk_" L "%=:\n"                                                                            \
+    "s_andn2_b64 vcc, vcc, %[take]\n"                                                                   \
+    "s_cselect_b32 %[" CUR "], %[ja], %[jb]\n"
+
+__device__ __forceinline__ void walk_two_groups_loop(const double4_t* rec4, uint32_t& ja_cur, uint32_t& jb_cur,
+                                                     uint32_t total_elems, uint32_t w2_lo, double softening, double pxa,
+                                                     double pya, double pxb, double pyb, double& axa, double& aya,
+                                                     double& axb, double& ayb, uint32_t& untila, uint32_t& untilb)
+{
+    double dx, dy, d2, y, y2;
+    unsigned long long take, saved_exec;
+    uint32_t off, ja, jb;
+    const double c15 = 1.5;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "s_max_u32 %[off], %[jA], %[jB]\n"
+        "s_cmp_lt_u32 %[off], %[tot]\n"
+        "s_cbranch_scc0 .Lpsim_walk_end%=\n"
+        ".Lpsim_walk_loop%=:\n"
+        "s_lshl_b32 %[off], %[jA], 5\n"
+        "s_load_dwordx8 s[40:47], %[rec], %[off]\n"
+        "s_lshl_b32 %[off], %[jB], 5\n"
+        "s_load_dwordx8 s[48:55], %[rec], %[off]\n"
+        "s_add_i32 %[ja], %[jA], 1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        PSIM_WALK_GROUP("s[40:41]", "s[42:43]", "s[44:45]", "s46", "s47", "s[46:47]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a")
+        "s_add_i32 %[ja], %[jB], 1\n"
+        PSIM_WALK_GROUP("s[48:49]", "s[50:51]", "s[52:53]", "s54", "s55", "s[54:55]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b")
+        "s_max_u32 %[off], %[jA], %[jB]\n"
+        "s_cmp_lt_u32 %[off], %[tot]\n"
+        "s_cbranch_scc1 .Lpsim_walk_loop%=\n"
+        ".Lpsim_walk_end%=:\n"
+        : [jA] "+s"(ja_cur), [jB] "+s"(jb_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [axB] "+v"(axb), [ayB] "+v"(ayb),
+          [uA] "+v"(untila), [uB] "+v"(untilb), [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y),
+          [y2] "=&v"(y2), [take] "=&s"(take), [sv] "=&s"(saved_exec), [off] "=&s"(off), [ja] "=&s"(ja), [jb] "=&s"(jb)
+        : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "s"(softening), [c15] "s"(c15),
+          [pxA] "v"(pxa), [pyA] "v"(pya), [pxB] "v"(pxb), [pyB] "v"(pyb)
+        : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+          "s54", "s55");
+}
+
+// One group alone (what is left of a wave's pair once the other group has finished): the same
+// trip with one fetch per turn.
+__device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint32_t& ja_cur, uint32_t total_elems,
+                                                    uint32_t w2_lo, double softening, double pxa, double pya, double& axa,
+                                                    double& aya, uint32_t& untila)
+{
+    double dx, dy, d2, y, y2;
+    unsigned long long take, saved_exec;
+    uint32_t off, ja, jb;
+    const double c15 = 1.5;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "s_cmp_lt_u32 %[jA], %[tot]\n"
+        "s_cbranch_scc0 .Lpsim_walk_end%=\n"
+        ".Lpsim_walk_loop%=:\n"
+        "s_lshl_b32 %[off], %[jA], 5\n"
+        "s_load_dwordx8 s[40:47], %[rec], %[off]\n"
+        "s_add_i32 %[ja], %[jA], 1\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        PSIM_WALK_GROUP("s[40:41]", "s[42:43]", "s[44:45]", "s46", "s47", "s[46:47]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a")
+        "s_cmp_lt_u32 %[jA], %[tot]\n"
+        "s_cbranch_scc1 .Lpsim_walk_loop%=\n"
+        ".Lpsim_walk_end%=:\n"
+        : [jA] "+s"(ja_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [uA] "+v"(untila), [dx] "=&v"(dx), [dy] "=&v"(dy),
+          [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [sv] "=&s"(saved_exec), [off] "=&s"(off),
+          [ja] "=&s"(ja), [jb] "=&s"(jb)
+        : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "s"(softening), [c15] "s"(c15),
+          [pxA] "v"(pxa), [pyA] "v"(pya)
+        : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
+}
+#undef PSIM_WALK_GROUP
+
 // K walks per wave: each lane carries one particle of each of K groups of 64
 // Morton-adjacent particles (the wave covers 64 K consecutive sorted particles), each
 // group with its own cursor.  The K elements are requested together, so one wait covers
@@ -998,7 +1109,9 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 // with the side stream's kernels, and a build that took 83 instead of 77 SGPRs (two more
 // pointer arguments, for a velocity kick fused into the epilogue) left those kernels 1.5x
 // slower under the walk (tools/kernel_resources.py lists what every kernel allocates).
-template <int K, bool FOLD, bool WIDE>
+// HAND (two groups, folded theta^2, 32-bit offsets only): the two-group loop is the
+// hand-scheduled one of walk_two_groups_loop below instead of the compiler's.
+template <int K, bool FOLD, bool WIDE, bool HAND = false>
 __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
@@ -1083,6 +1196,13 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
         // the kernel arguments the loop reads are pinned into registers here, so that the
         // compiler places no scalar-load wait of its own between the requests and their use
         asm volatile("" : "+s"(w2_lo), "+s"(theta2), "+s"(softening), "+s"(total_elems));
+        if constexpr (HAND) {
+            static_assert(K == 2 && FOLD, "the hand-scheduled loop is the two-group, folded one");
+            walk_two_groups_loop(rec4, j[0], j[1], total_elems, w2_lo, softening, px[0], py[0], px[1], py[1], ax[0], ay[0],
+                                 ax[1], ay[1], until[0], until[1]);
+            walk_one_group_loop(rec4, j[0], total_elems, w2_lo, softening, px[0], py[0], ax[0], ay[0], until[0]);
+            walk_one_group_loop(rec4, j[1], total_elems, w2_lo, softening, px[1], py[1], ax[1], ay[1], until[1]);
+        } else
         for (;;) {
             bool all = true;
 #pragma unroll
@@ -1098,9 +1218,11 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
             for (int k = 0; k < K; ++k) j[k] = trip(rv[k], j[k], px[k], py[k], ax[k], ay[k], until[k]);
         }
     }
+    if constexpr (!HAND) {
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-        while (j[k] < total_elems) j[k] = trip(fetch(j[k]), j[k], px[k], py[k], ax[k], ay[k], until[k]);
+        for (int k = 0; k < K; ++k)
+            while (j[k] < total_elems) j[k] = trip(fetch(j[k]), j[k], px[k], py[k], ax[k], ay[k], until[k]);
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int64_t kt = s0 + 64 * k;
@@ -1124,7 +1246,8 @@ template <int K>
 inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out, const NodeRec* rec, uint32_t total,
                               const vec2* spos, const double* smass, const uint32_t* perm, const uint32_t* order,
                               vec2* out, bool fold, uint32_t w2_lo, double theta2, double g_const, double softening,
-                              uint32_t* chunk_counter, int64_t resident_waves, bool force_wide = false)
+                              uint32_t* chunk_counter, int64_t resident_waves, bool force_wide = false,
+                              bool compiler_loop = false)
 {
     if (hi <= lo) return;
     // (the kernel reads `order` unconditionally: a null check in it costs two scalar registers,
@@ -1142,7 +1265,10 @@ inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out,
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
                            perm, order, out, w2_lo, theta2, g_const, softening, (uint32_t)chunks, chunk_counter);
     };
-    if (fold && !wide) go(gravity_walk_multi_kernel<K, true, false>);
+    if (fold && !wide) {
+        if (K == 2 && !compiler_loop) go(gravity_walk_multi_kernel<2, true, false, true>);
+        else go(gravity_walk_multi_kernel<K, true, false>);
+    }
     else if (fold) go(gravity_walk_multi_kernel<K, true, true>);
     else if (!wide) go(gravity_walk_multi_kernel<K, false, false>);
     else go(gravity_walk_multi_kernel<K, false, true>);

@@ -26,13 +26,14 @@ void Sim::gravity_range(int64_t lo, int64_t hi, vec2* out, bool sorted_out)
     uint32_t total = (uint32_t)(n + n_internal);
     double theta2 = cfg.theta * cfg.theta;          // particle_system.py:88 theta * theta * dist_sq
 #if !defined(PSIM_HOSTLOOP)
-    if (cfg.walk_mode == 0 || cfg.walk_mode == 3) {
-        // default: two walks per wave (3: with 64-bit element offsets forced, as on arrays of 4 GiB and more)
+    if (cfg.walk_mode == 0 || cfg.walk_mode == 3 || cfg.walk_mode == 5) {
+        // default: two walks per wave (3: with 64-bit element offsets forced, as on arrays of 4 GiB and more;
+        // 5: with the compiler's two-group loop instead of the hand-scheduled one)
         be::launch_walk_multi<2>(st, lo, hi, sorted_out ? 1 : 0, (const NodeRec*)rec.p, total, (const vec2*)spos.p,
                                  (const double*)smass.p, (const uint32_t*)perm[sorted_key].p,
                                  walk_order(), out, walk_fold, (uint32_t)w2_cmp_bits, theta2,
                                  cfg.gravity_constant, cfg.softening, walk_ctr.p, walk_resident_waves(),
-                                 cfg.walk_mode == 3);
+                                 cfg.walk_mode == 3, cfg.walk_mode == 5);
         return;
     }
     if (cfg.walk_mode == 2 || cfg.walk_mode == 4) {

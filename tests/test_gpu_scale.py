@@ -177,10 +177,11 @@ def test_first_step_contact_outputs_bit_exact_without_priming():
                               min_contacts=20000)
 
 
-@pytest.mark.parametrize("wide,narrow", [(3, 0), (4, 2)])
+@pytest.mark.parametrize("wide,narrow", [(3, 0), (4, 2), (5, 0)])
 def test_wide_offset_walk_equals_narrow(wide, narrow):
     """the walk kernels' 64-bit element offsets (taken for trees of 4 GiB and more, 2^27
-    elements) forced on at a small size: bit-identical accelerations and states"""
+    elements) forced on at a small size: bit-identical accelerations and states.  (5, 0): the
+    default walk's hand-scheduled loop against the same kernel with the compiler's loop."""
     n, bounds = 300000, (24000, 12500)
     a = ParticleSystem(n, dict(SIM), np.random.default_rng(5), bounds, walk_mode=narrow)
     b = ParticleSystem(n, dict(SIM), np.random.default_rng(5), bounds, walk_mode=wide)
