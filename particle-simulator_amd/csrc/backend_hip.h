@@ -1198,6 +1198,8 @@ __global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
         asm volatile("" : "+s"(w2_lo), "+s"(theta2), "+s"(softening), "+s"(total_elems));
         if constexpr (HAND) {
             static_assert(K == 2 && FOLD, "the hand-scheduled loop is the two-group, folded one");
+            // (three groups per wave with the same loop were measured: no faster alone, and the
+            // 90 scalar registers they need leave the side stream's kernels fewer waves)
             walk_two_groups_loop(rec4, j[0], j[1], total_elems, w2_lo, softening, px[0], py[0], px[1], py[1], ax[0], ay[0],
                                  ax[1], ay[1], until[0], until[1]);
             walk_one_group_loop(rec4, j[0], total_elems, w2_lo, softening, px[0], py[0], ax[0], ay[0], until[0]);
@@ -1266,8 +1268,12 @@ inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out,
                            perm, order, out, w2_lo, theta2, g_const, softening, (uint32_t)chunks, chunk_counter);
     };
     if (fold && !wide) {
-        if (K == 2 && !compiler_loop) go(gravity_walk_multi_kernel<2, true, false, true>);
-        else go(gravity_walk_multi_kernel<K, true, false>);
+        if constexpr (K == 2) {
+            if (!compiler_loop) go(gravity_walk_multi_kernel<2, true, false, true>);
+            else go(gravity_walk_multi_kernel<2, true, false>);
+        } else {
+            go(gravity_walk_multi_kernel<K, true, false>);
+        }
     }
     else if (fold) go(gravity_walk_multi_kernel<K, true, true>);
     else if (!wide) go(gravity_walk_multi_kernel<K, false, false>);

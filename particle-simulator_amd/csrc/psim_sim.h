@@ -205,12 +205,15 @@ public:
     // (Shifting slots from the walk to the side stream when the side work is the longer of the
     // two -- dense or clumped states -- was tried with a controller fed by the measured wait:
     // the step did not change; what one stream gains the other loses.)
+#ifndef PSIM_WALK_SLOTS
+#define PSIM_WALK_SLOTS 6.25         // wave slots per SIMD the walk holds while the side stream works (measured optimum)
+#endif
     int64_t walk_resident_waves() const
     {
         double per_simd = 0;
         if (cfg.overlap != 0 && n > 0) {
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
-            else per_simd = sharded_step ? 6 : 6.5;
+            else per_simd = sharded_step ? 6 : PSIM_WALK_SLOTS;
         }
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
