@@ -991,17 +991,25 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 
 // The two-group loop of gravity_walk_multi_kernel, scheduled by hand.  Same arithmetic in the
 // same order as the compiler's version of `trip` (results are bit-identical); what differs is
-// the scalar side.  Per group and trip the compiler's loop spends a third vector compare and
-// some eight scalar instructions on turning wave masks into booleans and back (is the element a
-// leaf, does any lane still want its children, has either cursor run out); every instruction
-// of a wave, scalar or vector, takes an issue turn of its SIMD, and the walk is bound by those
-// turns.  Here: the lanes that still want an element's children are the active ones that did not
-// accept, `active & ~take`, which is one s_andn2 whose SCC selects the next cursor directly;
-// a leaf needs no case of its own there (its skip is the next element, so both candidates are
-// equal); and the loop ends on an SCC branch.
-// Elements live in s[40:47] (group A) and s[48:55] (group B): {mass, x, y, skip, tag}.
+// the scalar side and the fetches.
+// - Per group and trip the compiler's loop spends a third vector compare and some eight scalar
+//   instructions on turning wave masks into booleans and back (is the element a leaf, does any
+//   lane still want its children, has either cursor run out).  Here the lanes that still want
+//   an element's children are the active ones that did not accept, `active & ~take`: one
+//   s_andn2 whose SCC selects the next cursor directly; a leaf needs no case of its own there
+//   (its skip is the next element, so both candidates are equal); the loop ends on an SCC branch.
+// - Each fetch brings the element at the cursor and the one after it (64 bytes; group A in
+//   s[40:55], group B in s[56:71]; an element is {mass, x, y, skip, tag}).  The next cursor is
+//   the following element on most turns (always after a leaf, and whenever some lane opens a
+//   node), and that element is then worked on straight away: no fetch, no wait.  The element
+//   array ends with one element of slack, so the fetch at the last element stays inside the
+//   allocation; what it brings is never used.
+// - Softening and the constant 1.5 sit in vector registers, EXEC (all lanes on entry: the
+//   kernel runs whole waves in uniform control flow) is put back as -1, and one scalar serves
+//   as fetch offset and as skip target: the kernel has to stay within 80 scalar registers,
+//   or the side stream's kernels lose the wave slots beside it.
 // v_rsq_f64 is followed by an independent instruction before its result is read, as the
-// compiler's schedule has it.  EXEC is all lanes on entry and is put back after each force block.
+// compiler's schedule has it.
 #define PSIM_WALK_GROUP(M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                         \
     "v_add_f64 %[dy], " Y ", -%[" PY "]\n"                                                              \
     "v_add_f64 %[dx], " X ", -%[" PX "]\n"                                                              \
@@ -1026,10 +1034,23 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     "v_mul_f64 %[d2], %[y], %[d2]\n"                                                                    \
     "v_fmac_f64 %[" AX "], %[d2], %[dx]\n"                                                              \
     "v_fmac_f64 %[" AY "], %[d2], %[dy]\n"                                                              \
-    "s_mov_b64 exec, %[sv]\n"                                                                           \
+    "s_mov_b64 exec, -1\n"                                                                              \
     ".Lpsim_walk_" L "%=:\n"                                                                            \
     "s_andn2_b64 vcc, vcc, %[take]\n"                                                                   \
     "s_cselect_b32 %[" CUR "], %[ja], %[jb]\n"
+// the element fetched along, when the cursor has moved onto it and it exists
+#define PSIM_WALK_SECOND(M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                        \
+    "s_cmp_lg_u32 %[" CUR "], %[ja]\n"                                                                  \
+    "s_cbranch_scc1 .Lpsim_walk_done_" L "%=\n"                                                         \
+    "s_cmp_ge_u32 %[" CUR "], %[tot]\n"                                                                 \
+    "s_cbranch_scc1 .Lpsim_walk_done_" L "%=\n"                                                         \
+    "s_add_i32 %[ja], %[" CUR "], 1\n"                                                                  \
+    PSIM_WALK_GROUP(M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                             \
+    ".Lpsim_walk_done_" L "%=:\n"
+#define PSIM_WALK_A1 PSIM_WALK_GROUP("s[40:41]", "s[42:43]", "s[44:45]", "s46", "s47", "s[46:47]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a")
+#define PSIM_WALK_A2 PSIM_WALK_SECOND("s[48:49]", "s[50:51]", "s[52:53]", "s54", "s55", "s[54:55]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a2")
+#define PSIM_WALK_B1 PSIM_WALK_GROUP("s[56:57]", "s[58:59]", "s[60:61]", "s62", "s63", "s[62:63]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b")
+#define PSIM_WALK_B2 PSIM_WALK_SECOND("s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[70:71]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b2")
 
 __device__ __forceinline__ void walk_two_groups_loop(const double4_t* rec4, uint32_t& ja_cur, uint32_t& jb_cur,
                                                      uint32_t total_elems, uint32_t w2_lo, double softening, double pxa,
@@ -1037,35 +1058,37 @@ __device__ __forceinline__ void walk_two_groups_loop(const double4_t* rec4, uint
                                                      double& axb, double& ayb, uint32_t& untila, uint32_t& untilb)
 {
     double dx, dy, d2, y, y2;
-    unsigned long long take, saved_exec;
-    uint32_t off, ja, jb;
+    unsigned long long take;
+    uint32_t ja, jb;
     const double c15 = 1.5;
     asm volatile(
-        "s_mov_b64 %[sv], exec\n"
-        "s_max_u32 %[off], %[jA], %[jB]\n"
-        "s_cmp_lt_u32 %[off], %[tot]\n"
+        "s_max_u32 %[jb], %[jA], %[jB]\n"
+        "s_cmp_lt_u32 %[jb], %[tot]\n"
         "s_cbranch_scc0 .Lpsim_walk_end%=\n"
         ".Lpsim_walk_loop%=:\n"
-        "s_lshl_b32 %[off], %[jA], 5\n"
-        "s_load_dwordx8 s[40:47], %[rec], %[off]\n"
-        "s_lshl_b32 %[off], %[jB], 5\n"
-        "s_load_dwordx8 s[48:55], %[rec], %[off]\n"
+        "s_lshl_b32 %[jb], %[jA], 5\n"
+        "s_load_dwordx16 s[40:55], %[rec], %[jb]\n"
+        "s_lshl_b32 %[jb], %[jB], 5\n"
+        "s_load_dwordx16 s[56:71], %[rec], %[jb]\n"
         "s_add_i32 %[ja], %[jA], 1\n"
         "s_waitcnt lgkmcnt(0)\n"
-        PSIM_WALK_GROUP("s[40:41]", "s[42:43]", "s[44:45]", "s46", "s47", "s[46:47]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a")
+        PSIM_WALK_A1
+        PSIM_WALK_A2
         "s_add_i32 %[ja], %[jB], 1\n"
-        PSIM_WALK_GROUP("s[48:49]", "s[50:51]", "s[52:53]", "s54", "s55", "s[54:55]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b")
-        "s_max_u32 %[off], %[jA], %[jB]\n"
-        "s_cmp_lt_u32 %[off], %[tot]\n"
+        PSIM_WALK_B1
+        PSIM_WALK_B2
+        "s_max_u32 %[jb], %[jA], %[jB]\n"
+        "s_cmp_lt_u32 %[jb], %[tot]\n"
         "s_cbranch_scc1 .Lpsim_walk_loop%=\n"
         ".Lpsim_walk_end%=:\n"
         : [jA] "+s"(ja_cur), [jB] "+s"(jb_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [axB] "+v"(axb), [ayB] "+v"(ayb),
           [uA] "+v"(untila), [uB] "+v"(untilb), [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y),
-          [y2] "=&v"(y2), [take] "=&s"(take), [sv] "=&s"(saved_exec), [off] "=&s"(off), [ja] "=&s"(ja), [jb] "=&s"(jb)
-        : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "s"(softening), [c15] "s"(c15),
+          [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb)
+        : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
           [pxA] "v"(pxa), [pyA] "v"(pya), [pxB] "v"(pxb), [pyB] "v"(pyb)
         : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-          "s54", "s55");
+          "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+          "s70", "s71");
 }
 
 // One group alone (what is left of a wave's pair once the other group has finished): the same
@@ -1075,29 +1098,34 @@ __device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint3
                                                     double& aya, uint32_t& untila)
 {
     double dx, dy, d2, y, y2;
-    unsigned long long take, saved_exec;
-    uint32_t off, ja, jb;
+    unsigned long long take;
+    uint32_t ja, jb;
     const double c15 = 1.5;
     asm volatile(
-        "s_mov_b64 %[sv], exec\n"
         "s_cmp_lt_u32 %[jA], %[tot]\n"
         "s_cbranch_scc0 .Lpsim_walk_end%=\n"
         ".Lpsim_walk_loop%=:\n"
-        "s_lshl_b32 %[off], %[jA], 5\n"
-        "s_load_dwordx8 s[40:47], %[rec], %[off]\n"
+        "s_lshl_b32 %[jb], %[jA], 5\n"
+        "s_load_dwordx16 s[40:55], %[rec], %[jb]\n"
         "s_add_i32 %[ja], %[jA], 1\n"
         "s_waitcnt lgkmcnt(0)\n"
-        PSIM_WALK_GROUP("s[40:41]", "s[42:43]", "s[44:45]", "s46", "s47", "s[46:47]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a")
+        PSIM_WALK_A1
+        PSIM_WALK_A2
         "s_cmp_lt_u32 %[jA], %[tot]\n"
         "s_cbranch_scc1 .Lpsim_walk_loop%=\n"
         ".Lpsim_walk_end%=:\n"
         : [jA] "+s"(ja_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [uA] "+v"(untila), [dx] "=&v"(dx), [dy] "=&v"(dy),
-          [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [sv] "=&s"(saved_exec), [off] "=&s"(off),
-          [ja] "=&s"(ja), [jb] "=&s"(jb)
-        : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "s"(softening), [c15] "s"(c15),
+          [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb)
+        : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
           [pxA] "v"(pxa), [pyA] "v"(pya)
-        : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
+        : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+          "s54", "s55");
 }
+#undef PSIM_WALK_A1
+#undef PSIM_WALK_A2
+#undef PSIM_WALK_B1
+#undef PSIM_WALK_B2
+#undef PSIM_WALK_SECOND
 #undef PSIM_WALK_GROUP
 
 // K walks per wave: each lane carries one particle of each of K groups of 64
@@ -1112,7 +1140,7 @@ __device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint3
 // HAND (two groups, folded theta^2, 32-bit offsets only): the two-group loop is the
 // hand-scheduled one of walk_two_groups_loop below instead of the compiler's.
 template <int K, bool FOLD, bool WIDE, bool HAND = false>
-__global__ void __launch_bounds__(64) gravity_walk_multi_kernel(
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) gravity_walk_multi_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
     const vec2* __restrict__ spos, const double* __restrict__ smass, const uint32_t* __restrict__ perm,
     const uint32_t* __restrict__ order, vec2* __restrict__ acc_out, uint32_t w2_lo, double theta2, double g_const,

@@ -205,15 +205,23 @@ public:
     // (Shifting slots from the walk to the side stream when the side work is the longer of the
     // two -- dense or clumped states -- was tried with a controller fed by the measured wait:
     // the step did not change; what one stream gains the other loses.)
-#ifndef PSIM_WALK_SLOTS
-#define PSIM_WALK_SLOTS 6.25         // wave slots per SIMD the walk holds while the side stream works (measured optimum)
+    // Wave slots per SIMD (of 8) the walk holds while the side stream works: measured optimum of
+    // the whole step (C2 4 Mi: 4.65 / 4.54 / 4.66 / 4.72 ms at 5.5 / 5.75 / 6 / 6.25; C3 16 Mi: 13.05 /
+    // 12.83 / 12.71 / 12.92).  PSIM_WALK_SLOTS overrides it at build time, for such sweeps.
+    double walk_slots_beside_collisions() const
+    {
+#ifdef PSIM_WALK_SLOTS
+        return PSIM_WALK_SLOTS;
+#else
+        return n >= (8ll << 20) ? 6.0 : 5.75;
 #endif
+    }
     int64_t walk_resident_waves() const
     {
         double per_simd = 0;
         if (cfg.overlap != 0 && n > 0) {
             if (!(cfg.stage_mask & kStageCollisions)) per_simd = n >= (8ll << 20) ? 7 : 0;
-            else per_simd = sharded_step ? 6 : PSIM_WALK_SLOTS;
+            else per_simd = sharded_step ? 6 : walk_slots_beside_collisions();
         }
         return per_simd > 0 ? (int64_t)(be::compute_units() * 4 * per_simd) : 0;
     }
@@ -656,7 +664,7 @@ public:
     }
     void ensure_tree_buffers(size_t mm)
     {
-        rec.ensure((size_t)n + mm);
+        rec.ensure((size_t)n + mm + 1);      // (one element of slack: the walk fetches elements two at a time)
         node_first.ensure(mm); node_last.ensure(mm); node_depth[0].ensure(mm); node_depth[1].ensure(mm);
         node_id[0].ensure(mm); node_id[1].ensure(mm); pe_node.ensure(mm);
     }
