@@ -21,13 +21,26 @@ from psim_amd.distributed import ShardedParticleSystem, shard_range
 
 def main():
     backend, library, name, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    # a rank that is still running after this many seconds prints where it is and exits
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("DIST_WORKER_DUMP_AFTER", "200")), exit=True)
     library = None if library == "hip" else library
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend, rank=rank, world_size=world)
-    g = load_golden(name)
     kw = dict(library=library, walk_mode=0 if library is None else 1, debug=True)
+    if name.startswith("c4:"):
+        # the dense hot disk of the benchmark's stress recipe at the given size: contacts in
+        # every slab, explosions from the first steps on
+        import types
+        import bench
+        _, n, bounds, state, _ = bench.workload("c4", int(name[3:]))
+        g = types.SimpleNamespace(n=n, sim=dict(bench.SIM), bounds=bounds, rng=lambda: np.random.default_rng(42),
+                                  init_velocities=lambda: None)
+        kw["state"] = state
+    else:
+        g = load_golden(name)
     ref = ParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds, **kw)
     sh = ShardedParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds, **kw)
     v = g.init_velocities()

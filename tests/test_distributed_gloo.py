@@ -45,7 +45,7 @@ def run_ranks(world, backend, library, name, steps, timeout=240):
 
 
 @pytest.mark.parametrize("world,name,steps", [(2, "dense256", 6), (2, "hot300", 6), (3, "fast200", 5),
-                                              (2, "dense400", 5), (3, "default2000", 4)])
+                                              (2, "dense400", 5), (3, "default2000", 4), (4, "c4:60000", 3)])
 def test_sharded_equals_unsharded(world, name, steps):
     subprocess.check_call(["make", "-s", "-C", HOSTLOOP_DIR])
     run_ranks(world, "gloo", HOSTLOOP, name, steps)
