@@ -59,7 +59,9 @@ typedef struct psim_config {
     int32_t walk_mode;                /* 0 = wave-cooperative tree walk, two particle groups per wave;
                                          1 = one lane per particle; 2 = wave-cooperative, one group per wave;
                                          3 / 4 = as 0 / 2 with the 64-bit element offsets the kernels switch to
-                                         for trees of 4 GiB and more forced on (tests) */
+                                         for trees of 4 GiB and more forced on (tests); 5 = as 0 with the
+                                         compiler's instruction schedule of the walk loop instead of the
+                                         hand-written one (tests: both must agree bit for bit) */
     int32_t debug;                    /* bit 0: keep the per-step contact log and delta-temperature array;
                                          bit 1: take the contact solver's large-hypothesis path at any size (tests) */
     int32_t overlap;                  /* 1 = run the grid build and the first contact-sweep count pass on a
