@@ -36,8 +36,13 @@ for case in range(cases):
         st = parity.gaussian_cluster_state(n, bounds, sigma, seed, 0.05, 0.1)
         name = "blob"
     elif kind == 2:
-        st = parity.tight_pairs_state(n, bounds, seed, pairs=max(1, n // int(rng.integers(4, 60))), gap=10.0 ** -float(rng.uniform(1, 5)),
-                                      box=float(rng.uniform(5.0, min(bounds) / 2)))
+        # (the couples' square holds them at no more than about two discs deep, for the same reason)
+        pairs = max(1, n // int(rng.integers(4, 60)))
+        box = max(float(rng.uniform(5.0, min(bounds) / 2)), float(np.sqrt(30.0 * pairs)))
+        while box > min(bounds) / 2:
+            pairs = max(1, pairs // 2)
+            box = max(5.0, float(np.sqrt(30.0 * pairs)))
+        st = parity.tight_pairs_state(n, bounds, seed, pairs=pairs, gap=10.0 ** -float(rng.uniform(1, 5)), box=box)
         name = "pairs"
     else:
         st = parity.clustered_state(n, bounds, seed, clusters=max(1, n // 500), per=int(rng.integers(2, 9)), spread=10.0 ** -float(rng.uniform(1, 4)))
