@@ -1137,8 +1137,10 @@ __device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint3
 // with the side stream's kernels, and a build that took 83 instead of 77 SGPRs (two more
 // pointer arguments, for a velocity kick fused into the epilogue) left those kernels 1.5x
 // slower under the walk (tools/kernel_resources.py lists what every kernel allocates).
-// HAND (two groups, folded theta^2, 32-bit offsets only): the two-group loop is the
-// hand-scheduled one of walk_two_groups_loop below instead of the compiler's.
+// amdgpu_num_sgpr(80) holds every variant at the 80-register allocation step.
+// HAND (two groups, folded theta^2, 32-bit offsets only): the two-group loop and the one-group
+// tails are the hand-scheduled ones above (walk_two_groups_loop, walk_one_group_loop) instead
+// of the compiler's.
 template <int K, bool FOLD, bool WIDE, bool HAND = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) gravity_walk_multi_kernel(
     int64_t s_begin, int64_t s_end, int sorted_out, const NodeRec* __restrict__ rec, uint32_t total_elems,
