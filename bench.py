@@ -118,7 +118,7 @@ def launch_ranks(n_ranks):
         port = sk.getsockname()[1]
     procs = []
     for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if "--one-device" in sys.argv else str(r), WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -149,6 +149,9 @@ def main():
                     help="alternative build of the library (kernel experiments; the test-only host-loop build, "
                          "with --backend gloo, for the CPU test of the multi-rank path)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--one-device", action="store_true",
+                    help="with --gpus N --backend gloo: every rank on GPU 0 (a rehearsal of the multi-rank path on a "
+                         "one-GPU box; the ranks share the device, so the timings mean nothing)")
     ap.add_argument("--staged", action="store_true",
                     help="drive the step through the psim_stage_* entry points (the multi-GPU path) even on one GPU")
     ap.add_argument("--no-overlap", action="store_true",
