@@ -22,6 +22,7 @@ timeout -k 10 200 python tools/drift_report.py > $O/${P}_drift_c0.txt 2> $O/drif
 cd /tmp && export TMPDIR=/tmp
 step kernel stats
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --no-cpu-baseline --brute 0 > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -o c3 -- python3 $R/bench.py --no-cpu-baseline --brute 0 --workload c3 --steps 5 --warmup 2 > $O/stats3.log 2>&1 || exit 1
 step timelines
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/tl -o tl -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 5 > $O/tl.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/tl3 -o tl -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 3 --warmup 2 --workload c3 > $O/tl3.log 2>&1 || exit 1
@@ -43,5 +44,6 @@ python3 tools/pmc_summary.py $(db pmc) gravity_walk_multi > $O/${P}_walk_pmc_raw
 python3 tools/pmc_summary.py $(db hb_f) gravity_walk_multi > $O/${P}_walk_fetch_raw.txt
 python3 tools/pmc_summary.py $(db hb_w) gravity_walk_multi > $O/${P}_walk_write_raw.txt
 cp $(ls $O/stats/*/*kernel_stats.csv $O/stats/*kernel_stats.csv 2>/dev/null | head -1) $O/${P}_bench_c2_kernel_stats.csv
-rm -rf $O/stats $O/tl $O/tl3 $O/hb_t $O/hb3_t $O/hb_f $O/hb_w $O/pmc
+cp $(ls $O/stats3/*/*kernel_stats.csv $O/stats3/*kernel_stats.csv 2>/dev/null | head -1) $O/${P}_bench_c3_kernel_stats.csv
+rm -rf $O/stats $O/stats3 $O/tl $O/tl3 $O/hb_t $O/hb3_t $O/hb_f $O/hb_w $O/pmc
 ls -la $O
