@@ -1010,7 +1010,7 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 //   or the side stream's kernels lose the wave slots beside it.
 // v_rsq_f64 is followed by an independent instruction before its result is read, as the
 // compiler's schedule has it.
-#define PSIM_WALK_GROUP(M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                         \
+#define PSIM_WALK_GROUP(ACCEPT, M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                 \
     "v_add_f64 %[dy], " Y ", -%[" PY "]\n"                                                              \
     "v_add_f64 %[dx], " X ", -%[" PX "]\n"                                                              \
     "s_max_u32 %[jb], " SKIP ", %[ja]\n"                                                                \
@@ -1019,7 +1019,7 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     "s_cselect_b32 " SKIP ", %[w2lo], 0\n"                                                              \
     "v_fmac_f64 %[d2], %[dx], %[dx]\n"                                                                  \
     "v_cmp_ge_u32 vcc, %[" CUR "], %[" UNTIL "]\n"                                                      \
-    "v_cmp_lt_f64 %[take], " LHS ", %[d2]\n"                                                            \
+    ACCEPT(LHS)                                                                                         \
     "s_and_b64 %[take], vcc, %[take]\n"                                                                 \
     "s_cbranch_scc0 .Lpsim_walk_" L "%=\n"                                                              \
     "s_mov_b64 exec, %[take]\n"                                                                         \
@@ -1038,94 +1038,137 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     ".Lpsim_walk_" L "%=:\n"                                                                            \
     "s_andn2_b64 vcc, vcc, %[take]\n"                                                                   \
     "s_cselect_b32 %[" CUR "], %[ja], %[jb]\n"
+// The acceptance test.  Folded (theta^2 a power of two, divided into the elements' tags): lhs < d^2.
+// Scaled (any theta): lhs < theta^2 d^2 for a node, lhs = 0 < d^2 for a leaf; the factor is
+// picked by the SCC the leaf test just left (s_cselect reads it, nothing in between writes it).
+#define PSIM_WALK_ACCEPT_FOLDED(LHS) "v_cmp_lt_f64 %[take], " LHS ", %[d2]\n"
+#define PSIM_WALK_ACCEPT_SCALED(LHS)                                                                    \
+    "s_cselect_b64 %[sc], %[th2], %[one]\n"                                                             \
+    "v_mul_f64 %[y2], %[sc], %[d2]\n"                                                                   \
+    "v_cmp_lt_f64 %[take], " LHS ", %[y2]\n"
 // the element fetched along, when the cursor has moved onto it and it exists
-#define PSIM_WALK_SECOND(M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                        \
+#define PSIM_WALK_SECOND(ACCEPT, M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                \
     "s_cmp_lg_u32 %[" CUR "], %[ja]\n"                                                                  \
     "s_cbranch_scc1 .Lpsim_walk_done_" L "%=\n"                                                         \
     "s_cmp_ge_u32 %[" CUR "], %[tot]\n"                                                                 \
     "s_cbranch_scc1 .Lpsim_walk_done_" L "%=\n"                                                         \
     "s_add_i32 %[ja], %[" CUR "], 1\n"                                                                  \
-    PSIM_WALK_GROUP(M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                             \
+    PSIM_WALK_GROUP(ACCEPT, M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                     \
     ".Lpsim_walk_done_" L "%=:\n"
-#define PSIM_WALK_A1 PSIM_WALK_GROUP("s[40:41]", "s[42:43]", "s[44:45]", "s46", "s47", "s[46:47]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a")
-#define PSIM_WALK_A2 PSIM_WALK_SECOND("s[48:49]", "s[50:51]", "s[52:53]", "s54", "s55", "s[54:55]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a2")
-#define PSIM_WALK_B1 PSIM_WALK_GROUP("s[56:57]", "s[58:59]", "s[60:61]", "s62", "s63", "s[62:63]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b")
-#define PSIM_WALK_B2 PSIM_WALK_SECOND("s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[70:71]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b2")
+#define PSIM_WALK_A1(ACC) PSIM_WALK_GROUP(ACC, "s[40:41]", "s[42:43]", "s[44:45]", "s46", "s47", "s[46:47]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a")
+#define PSIM_WALK_A2(ACC) PSIM_WALK_SECOND(ACC, "s[48:49]", "s[50:51]", "s[52:53]", "s54", "s55", "s[54:55]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a2")
+#define PSIM_WALK_B1(ACC) PSIM_WALK_GROUP(ACC, "s[56:57]", "s[58:59]", "s[60:61]", "s62", "s63", "s[62:63]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b")
+#define PSIM_WALK_B2(ACC) PSIM_WALK_SECOND(ACC, "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[70:71]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b2")
+#define PSIM_WALK_TWO(ACC)                                                                               \
+        "s_max_u32 %[jb], %[jA], %[jB]\n"                                                               \
+        "s_cmp_lt_u32 %[jb], %[tot]\n"                                                                  \
+        "s_cbranch_scc0 .Lpsim_walk_end%=\n"                                                            \
+        ".Lpsim_walk_loop%=:\n"                                                                         \
+        "s_lshl_b32 %[jb], %[jA], 5\n"                                                                  \
+        "s_load_dwordx16 s[40:55], %[rec], %[jb]\n"                                                     \
+        "s_lshl_b32 %[jb], %[jB], 5\n"                                                                  \
+        "s_load_dwordx16 s[56:71], %[rec], %[jb]\n"                                                     \
+        "s_add_i32 %[ja], %[jA], 1\n"                                                                   \
+        "s_waitcnt lgkmcnt(0)\n"                                                                        \
+        PSIM_WALK_A1(ACC)                                                                               \
+        PSIM_WALK_A2(ACC)                                                                               \
+        "s_add_i32 %[ja], %[jB], 1\n"                                                                   \
+        PSIM_WALK_B1(ACC)                                                                               \
+        PSIM_WALK_B2(ACC)                                                                               \
+        "s_max_u32 %[jb], %[jA], %[jB]\n"                                                               \
+        "s_cmp_lt_u32 %[jb], %[tot]\n"                                                                  \
+        "s_cbranch_scc1 .Lpsim_walk_loop%=\n"                                                           \
+        ".Lpsim_walk_end%=:\n"
+#define PSIM_WALK_ONE(ACC)                                                                               \
+        "s_cmp_lt_u32 %[jA], %[tot]\n"                                                                  \
+        "s_cbranch_scc0 .Lpsim_walk_end%=\n"                                                            \
+        ".Lpsim_walk_loop%=:\n"                                                                         \
+        "s_lshl_b32 %[jb], %[jA], 5\n"                                                                  \
+        "s_load_dwordx16 s[40:55], %[rec], %[jb]\n"                                                     \
+        "s_add_i32 %[ja], %[jA], 1\n"                                                                   \
+        "s_waitcnt lgkmcnt(0)\n"                                                                        \
+        PSIM_WALK_A1(ACC)                                                                               \
+        PSIM_WALK_A2(ACC)                                                                               \
+        "s_cmp_lt_u32 %[jA], %[tot]\n"                                                                  \
+        "s_cbranch_scc1 .Lpsim_walk_loop%=\n"                                                           \
+        ".Lpsim_walk_end%=:\n"
+#define PSIM_WALK_CLOBBERS_A "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
+#define PSIM_WALK_CLOBBERS_B "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
 
+// FOLD: see gravity_walk_multi_kernel; theta2 is only read when it is false.
+template <bool FOLD>
 __device__ __forceinline__ void walk_two_groups_loop(const double4_t* rec4, uint32_t& ja_cur, uint32_t& jb_cur,
-                                                     uint32_t total_elems, uint32_t w2_lo, double softening, double pxa,
-                                                     double pya, double pxb, double pyb, double& axa, double& aya,
-                                                     double& axb, double& ayb, uint32_t& untila, uint32_t& untilb)
+                                                     uint32_t total_elems, uint32_t w2_lo, double theta2, double softening,
+                                                     double pxa, double pya, double pxb, double pyb, double& axa,
+                                                     double& aya, double& axb, double& ayb, uint32_t& untila,
+                                                     uint32_t& untilb)
 {
     double dx, dy, d2, y, y2;
     unsigned long long take;
     uint32_t ja, jb;
     const double c15 = 1.5;
-    asm volatile(
-        "s_max_u32 %[jb], %[jA], %[jB]\n"
-        "s_cmp_lt_u32 %[jb], %[tot]\n"
-        "s_cbranch_scc0 .Lpsim_walk_end%=\n"
-        ".Lpsim_walk_loop%=:\n"
-        "s_lshl_b32 %[jb], %[jA], 5\n"
-        "s_load_dwordx16 s[40:55], %[rec], %[jb]\n"
-        "s_lshl_b32 %[jb], %[jB], 5\n"
-        "s_load_dwordx16 s[56:71], %[rec], %[jb]\n"
-        "s_add_i32 %[ja], %[jA], 1\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        PSIM_WALK_A1
-        PSIM_WALK_A2
-        "s_add_i32 %[ja], %[jB], 1\n"
-        PSIM_WALK_B1
-        PSIM_WALK_B2
-        "s_max_u32 %[jb], %[jA], %[jB]\n"
-        "s_cmp_lt_u32 %[jb], %[tot]\n"
-        "s_cbranch_scc1 .Lpsim_walk_loop%=\n"
-        ".Lpsim_walk_end%=:\n"
-        : [jA] "+s"(ja_cur), [jB] "+s"(jb_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [axB] "+v"(axb), [ayB] "+v"(ayb),
-          [uA] "+v"(untila), [uB] "+v"(untilb), [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y),
-          [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb)
-        : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
-          [pxA] "v"(pxa), [pyA] "v"(pya), [pxB] "v"(pxb), [pyB] "v"(pyb)
-        : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-          "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
-          "s70", "s71");
+    if constexpr (FOLD) {
+        asm volatile(PSIM_WALK_TWO(PSIM_WALK_ACCEPT_FOLDED)
+            : [jA] "+s"(ja_cur), [jB] "+s"(jb_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [axB] "+v"(axb), [ayB] "+v"(ayb),
+              [uA] "+v"(untila), [uB] "+v"(untilb), [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y),
+              [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb)
+            : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
+              [pxA] "v"(pxa), [pyA] "v"(pya), [pxB] "v"(pxb), [pyB] "v"(pyb)
+            : PSIM_WALK_CLOBBERS_A, PSIM_WALK_CLOBBERS_B);
+    } else {
+        double scale;
+        const double one = 1.0;
+        asm volatile(PSIM_WALK_TWO(PSIM_WALK_ACCEPT_SCALED)
+            : [jA] "+s"(ja_cur), [jB] "+s"(jb_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [axB] "+v"(axb), [ayB] "+v"(ayb),
+              [uA] "+v"(untila), [uB] "+v"(untilb), [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y),
+              [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb), [sc] "=&s"(scale)
+            : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
+              [pxA] "v"(pxa), [pyA] "v"(pya), [pxB] "v"(pxb), [pyB] "v"(pyb), [th2] "s"(theta2), [one] "s"(one)
+            : PSIM_WALK_CLOBBERS_A, PSIM_WALK_CLOBBERS_B);
+    }
 }
 
 // One group alone (what is left of a wave's pair once the other group has finished): the same
 // trip with one fetch per turn.
+template <bool FOLD>
 __device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint32_t& ja_cur, uint32_t total_elems,
-                                                    uint32_t w2_lo, double softening, double pxa, double pya, double& axa,
-                                                    double& aya, uint32_t& untila)
+                                                    uint32_t w2_lo, double theta2, double softening, double pxa, double pya,
+                                                    double& axa, double& aya, uint32_t& untila)
 {
     double dx, dy, d2, y, y2;
     unsigned long long take;
     uint32_t ja, jb;
     const double c15 = 1.5;
-    asm volatile(
-        "s_cmp_lt_u32 %[jA], %[tot]\n"
-        "s_cbranch_scc0 .Lpsim_walk_end%=\n"
-        ".Lpsim_walk_loop%=:\n"
-        "s_lshl_b32 %[jb], %[jA], 5\n"
-        "s_load_dwordx16 s[40:55], %[rec], %[jb]\n"
-        "s_add_i32 %[ja], %[jA], 1\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        PSIM_WALK_A1
-        PSIM_WALK_A2
-        "s_cmp_lt_u32 %[jA], %[tot]\n"
-        "s_cbranch_scc1 .Lpsim_walk_loop%=\n"
-        ".Lpsim_walk_end%=:\n"
-        : [jA] "+s"(ja_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [uA] "+v"(untila), [dx] "=&v"(dx), [dy] "=&v"(dy),
-          [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb)
-        : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
-          [pxA] "v"(pxa), [pyA] "v"(pya)
-        : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-          "s54", "s55");
+    if constexpr (FOLD) {
+        asm volatile(PSIM_WALK_ONE(PSIM_WALK_ACCEPT_FOLDED)
+            : [jA] "+s"(ja_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [uA] "+v"(untila), [dx] "=&v"(dx), [dy] "=&v"(dy),
+              [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb)
+            : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
+              [pxA] "v"(pxa), [pyA] "v"(pya)
+            : PSIM_WALK_CLOBBERS_A);
+    } else {
+        double scale;
+        const double one = 1.0;
+        asm volatile(PSIM_WALK_ONE(PSIM_WALK_ACCEPT_SCALED)
+            : [jA] "+s"(ja_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [uA] "+v"(untila), [dx] "=&v"(dx), [dy] "=&v"(dy),
+              [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb),
+              [sc] "=&s"(scale)
+            : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
+              [pxA] "v"(pxa), [pyA] "v"(pya), [th2] "s"(theta2), [one] "s"(one)
+            : PSIM_WALK_CLOBBERS_A);
+    }
 }
+#undef PSIM_WALK_CLOBBERS_A
+#undef PSIM_WALK_CLOBBERS_B
+#undef PSIM_WALK_ONE
+#undef PSIM_WALK_TWO
 #undef PSIM_WALK_A1
 #undef PSIM_WALK_A2
 #undef PSIM_WALK_B1
 #undef PSIM_WALK_B2
 #undef PSIM_WALK_SECOND
+#undef PSIM_WALK_ACCEPT_FOLDED
+#undef PSIM_WALK_ACCEPT_SCALED
 #undef PSIM_WALK_GROUP
 
 // K walks per wave: each lane carries one particle of each of K groups of 64
@@ -1138,7 +1181,7 @@ __device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint3
 // pointer arguments, for a velocity kick fused into the epilogue) left those kernels 1.5x
 // slower under the walk (tools/kernel_resources.py lists what every kernel allocates).
 // amdgpu_num_sgpr(80) holds every variant at the 80-register allocation step.
-// HAND (two groups, folded theta^2, 32-bit offsets only): the two-group loop and the one-group
+// HAND (two groups, 32-bit offsets only): the two-group loop and the one-group
 // tails are the hand-scheduled ones above (walk_two_groups_loop, walk_one_group_loop) instead
 // of the compiler's.
 template <int K, bool FOLD, bool WIDE, bool HAND = false>
@@ -1227,13 +1270,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) gravi
         // compiler places no scalar-load wait of its own between the requests and their use
         asm volatile("" : "+s"(w2_lo), "+s"(theta2), "+s"(softening), "+s"(total_elems));
         if constexpr (HAND) {
-            static_assert(K == 2 && FOLD, "the hand-scheduled loop is the two-group, folded one");
+            static_assert(K == 2, "the hand-scheduled loop is the two-group one");
             // (three groups per wave with the same loop were measured: no faster alone, and the
             // 90 scalar registers they need leave the side stream's kernels fewer waves)
-            walk_two_groups_loop(rec4, j[0], j[1], total_elems, w2_lo, softening, px[0], py[0], px[1], py[1], ax[0], ay[0],
-                                 ax[1], ay[1], until[0], until[1]);
-            walk_one_group_loop(rec4, j[0], total_elems, w2_lo, softening, px[0], py[0], ax[0], ay[0], until[0]);
-            walk_one_group_loop(rec4, j[1], total_elems, w2_lo, softening, px[1], py[1], ax[1], ay[1], until[1]);
+            walk_two_groups_loop<FOLD>(rec4, j[0], j[1], total_elems, w2_lo, theta2, softening, px[0], py[0], px[1], py[1],
+                                       ax[0], ay[0], ax[1], ay[1], until[0], until[1]);
+            walk_one_group_loop<FOLD>(rec4, j[0], total_elems, w2_lo, theta2, softening, px[0], py[0], ax[0], ay[0], until[0]);
+            walk_one_group_loop<FOLD>(rec4, j[1], total_elems, w2_lo, theta2, softening, px[1], py[1], ax[1], ay[1], until[1]);
         } else
         for (;;) {
             bool all = true;
@@ -1306,7 +1349,14 @@ inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out,
         }
     }
     else if (fold) go(gravity_walk_multi_kernel<K, true, true>);
-    else if (!wide) go(gravity_walk_multi_kernel<K, false, false>);
+    else if (!wide) {
+        if constexpr (K == 2) {
+            if (!compiler_loop) go(gravity_walk_multi_kernel<2, false, false, true>);
+            else go(gravity_walk_multi_kernel<2, false, false>);
+        } else {
+            go(gravity_walk_multi_kernel<K, false, false>);
+        }
+    }
     else go(gravity_walk_multi_kernel<K, false, true>);
     PSIM_HIP(hipGetLastError());
 }
