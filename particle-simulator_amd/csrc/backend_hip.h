@@ -1059,15 +1059,24 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 #define PSIM_WALK_A2(ACC) PSIM_WALK_SECOND(ACC, "s[48:49]", "s[50:51]", "s[52:53]", "s54", "s55", "s[54:55]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a2")
 #define PSIM_WALK_B1(ACC) PSIM_WALK_GROUP(ACC, "s[56:57]", "s[58:59]", "s[60:61]", "s62", "s63", "s[62:63]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b")
 #define PSIM_WALK_B2(ACC) PSIM_WALK_SECOND(ACC, "s[64:65]", "s[66:67]", "s[68:69]", "s70", "s71", "s[70:71]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b2")
-#define PSIM_WALK_TWO(ACC)                                                                               \
+// The fetch of two elements at a cursor: a 32-bit byte offset from the array's base, or, for
+// arrays of 4 GiB and more, the 64-bit address formed in s[38:39].
+#define PSIM_WALK_FETCH_NARROW(DST, CUR)                                                                \
+        "s_lshl_b32 %[jb], %[" CUR "], 5\n"                                                             \
+        "s_load_dwordx16 " DST ", %[rec], %[jb]\n"
+#define PSIM_WALK_FETCH_WIDE(DST, CUR)                                                                  \
+        "s_lshl_b32 s38, %[" CUR "], 5\n"                                                               \
+        "s_lshr_b32 s39, %[" CUR "], 27\n"                                                              \
+        "s_add_u32 s38, s38, %[reclo]\n"                                                                \
+        "s_addc_u32 s39, s39, %[rechi]\n"                                                               \
+        "s_load_dwordx16 " DST ", s[38:39], 0x0\n"
+#define PSIM_WALK_TWO(ACC, FETCH)                                                                        \
         "s_max_u32 %[jb], %[jA], %[jB]\n"                                                               \
         "s_cmp_lt_u32 %[jb], %[tot]\n"                                                                  \
         "s_cbranch_scc0 .Lpsim_walk_end%=\n"                                                            \
         ".Lpsim_walk_loop%=:\n"                                                                         \
-        "s_lshl_b32 %[jb], %[jA], 5\n"                                                                  \
-        "s_load_dwordx16 s[40:55], %[rec], %[jb]\n"                                                     \
-        "s_lshl_b32 %[jb], %[jB], 5\n"                                                                  \
-        "s_load_dwordx16 s[56:71], %[rec], %[jb]\n"                                                     \
+        FETCH("s[40:55]", "jA")                                                                         \
+        FETCH("s[56:71]", "jB")                                                                         \
         "s_add_i32 %[ja], %[jA], 1\n"                                                                   \
         "s_waitcnt lgkmcnt(0)\n"                                                                        \
         PSIM_WALK_A1(ACC)                                                                               \
@@ -1079,12 +1088,11 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
         "s_cmp_lt_u32 %[jb], %[tot]\n"                                                                  \
         "s_cbranch_scc1 .Lpsim_walk_loop%=\n"                                                           \
         ".Lpsim_walk_end%=:\n"
-#define PSIM_WALK_ONE(ACC)                                                                               \
+#define PSIM_WALK_ONE(ACC, FETCH)                                                                        \
         "s_cmp_lt_u32 %[jA], %[tot]\n"                                                                  \
         "s_cbranch_scc0 .Lpsim_walk_end%=\n"                                                            \
         ".Lpsim_walk_loop%=:\n"                                                                         \
-        "s_lshl_b32 %[jb], %[jA], 5\n"                                                                  \
-        "s_load_dwordx16 s[40:55], %[rec], %[jb]\n"                                                     \
+        FETCH("s[40:55]", "jA")                                                                         \
         "s_add_i32 %[ja], %[jA], 1\n"                                                                   \
         "s_waitcnt lgkmcnt(0)\n"                                                                        \
         PSIM_WALK_A1(ACC)                                                                               \
@@ -1095,8 +1103,33 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 #define PSIM_WALK_CLOBBERS_A "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
 #define PSIM_WALK_CLOBBERS_B "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
 
-// FOLD: see gravity_walk_multi_kernel; theta2 is only read when it is false.
-template <bool FOLD>
+#define PSIM_WALK_IN_NARROW , [rec] "s"(rec4)
+#define PSIM_WALK_IN_WIDE , [reclo] "s"(rec_lo), [rechi] "s"(rec_hi)
+#define PSIM_WALK_CLOB_NARROW
+#define PSIM_WALK_CLOB_WIDE , "s38", "s39"
+#define PSIM_WALK_IN_FOLDED
+#define PSIM_WALK_IN_SCALED , [th2] "s"(theta2), [one] "s"(one)
+#define PSIM_WALK_OUT_FOLDED
+#define PSIM_WALK_OUT_SCALED , [sc] "=&s"(scale)
+#define PSIM_WALK_ASM_TWO(A, F)                                                                                          \
+    asm volatile(PSIM_WALK_TWO(PSIM_WALK_ACCEPT_##A, PSIM_WALK_FETCH_##F)                                                \
+        : [jA] "+s"(ja_cur), [jB] "+s"(jb_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [axB] "+v"(axb), [ayB] "+v"(ayb),      \
+          [uA] "+v"(untila), [uB] "+v"(untilb), [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y),            \
+          [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb) PSIM_WALK_OUT_##A                           \
+        : [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15), [pxA] "v"(pxa),              \
+          [pyA] "v"(pya), [pxB] "v"(pxb), [pyB] "v"(pyb) PSIM_WALK_IN_##A PSIM_WALK_IN_##F                               \
+        : PSIM_WALK_CLOBBERS_A, PSIM_WALK_CLOBBERS_B PSIM_WALK_CLOB_##F)
+#define PSIM_WALK_ASM_ONE(A, F)                                                                                          \
+    asm volatile(PSIM_WALK_ONE(PSIM_WALK_ACCEPT_##A, PSIM_WALK_FETCH_##F)                                                \
+        : [jA] "+s"(ja_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [uA] "+v"(untila), [dx] "=&v"(dx), [dy] "=&v"(dy),        \
+          [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja),                              \
+          [jb] "=&s"(jb) PSIM_WALK_OUT_##A                                                                               \
+        : [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15), [pxA] "v"(pxa),              \
+          [pyA] "v"(pya) PSIM_WALK_IN_##A PSIM_WALK_IN_##F                                                               \
+        : PSIM_WALK_CLOBBERS_A PSIM_WALK_CLOB_##F)
+
+// FOLD, WIDE: see gravity_walk_multi_kernel; theta2 is only read when FOLD is false.
+template <bool FOLD, bool WIDE>
 __device__ __forceinline__ void walk_two_groups_loop(const double4_t* rec4, uint32_t& ja_cur, uint32_t& jb_cur,
                                                      uint32_t total_elems, uint32_t w2_lo, double theta2, double softening,
                                                      double pxa, double pya, double pxb, double pyb, double& axa,
@@ -1107,30 +1140,19 @@ __device__ __forceinline__ void walk_two_groups_loop(const double4_t* rec4, uint
     unsigned long long take;
     uint32_t ja, jb;
     const double c15 = 1.5;
-    if constexpr (FOLD) {
-        asm volatile(PSIM_WALK_TWO(PSIM_WALK_ACCEPT_FOLDED)
-            : [jA] "+s"(ja_cur), [jB] "+s"(jb_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [axB] "+v"(axb), [ayB] "+v"(ayb),
-              [uA] "+v"(untila), [uB] "+v"(untilb), [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y),
-              [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb)
-            : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
-              [pxA] "v"(pxa), [pyA] "v"(pya), [pxB] "v"(pxb), [pyB] "v"(pyb)
-            : PSIM_WALK_CLOBBERS_A, PSIM_WALK_CLOBBERS_B);
-    } else {
-        double scale;
-        const double one = 1.0;
-        asm volatile(PSIM_WALK_TWO(PSIM_WALK_ACCEPT_SCALED)
-            : [jA] "+s"(ja_cur), [jB] "+s"(jb_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [axB] "+v"(axb), [ayB] "+v"(ayb),
-              [uA] "+v"(untila), [uB] "+v"(untilb), [dx] "=&v"(dx), [dy] "=&v"(dy), [d2] "=&v"(d2), [y] "=&v"(y),
-              [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb), [sc] "=&s"(scale)
-            : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
-              [pxA] "v"(pxa), [pyA] "v"(pya), [pxB] "v"(pxb), [pyB] "v"(pyb), [th2] "s"(theta2), [one] "s"(one)
-            : PSIM_WALK_CLOBBERS_A, PSIM_WALK_CLOBBERS_B);
-    }
+    [[maybe_unused]] double scale;
+    [[maybe_unused]] const double one = 1.0;
+    [[maybe_unused]] const uint32_t rec_lo = (uint32_t)reinterpret_cast<uintptr_t>(rec4);
+    [[maybe_unused]] const uint32_t rec_hi = (uint32_t)(reinterpret_cast<uintptr_t>(rec4) >> 32);
+    if constexpr (FOLD && !WIDE) PSIM_WALK_ASM_TWO(FOLDED, NARROW);
+    else if constexpr (FOLD) PSIM_WALK_ASM_TWO(FOLDED, WIDE);
+    else if constexpr (!WIDE) PSIM_WALK_ASM_TWO(SCALED, NARROW);
+    else PSIM_WALK_ASM_TWO(SCALED, WIDE);
 }
 
 // One group alone (what is left of a wave's pair once the other group has finished): the same
 // trip with one fetch per turn.
-template <bool FOLD>
+template <bool FOLD, bool WIDE>
 __device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint32_t& ja_cur, uint32_t total_elems,
                                                     uint32_t w2_lo, double theta2, double softening, double pxa, double pya,
                                                     double& axa, double& aya, uint32_t& untila)
@@ -1139,25 +1161,27 @@ __device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint3
     unsigned long long take;
     uint32_t ja, jb;
     const double c15 = 1.5;
-    if constexpr (FOLD) {
-        asm volatile(PSIM_WALK_ONE(PSIM_WALK_ACCEPT_FOLDED)
-            : [jA] "+s"(ja_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [uA] "+v"(untila), [dx] "=&v"(dx), [dy] "=&v"(dy),
-              [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb)
-            : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
-              [pxA] "v"(pxa), [pyA] "v"(pya)
-            : PSIM_WALK_CLOBBERS_A);
-    } else {
-        double scale;
-        const double one = 1.0;
-        asm volatile(PSIM_WALK_ONE(PSIM_WALK_ACCEPT_SCALED)
-            : [jA] "+s"(ja_cur), [axA] "+v"(axa), [ayA] "+v"(aya), [uA] "+v"(untila), [dx] "=&v"(dx), [dy] "=&v"(dy),
-              [d2] "=&v"(d2), [y] "=&v"(y), [y2] "=&v"(y2), [take] "=&s"(take), [ja] "=&s"(ja), [jb] "=&s"(jb),
-              [sc] "=&s"(scale)
-            : [rec] "s"(rec4), [tot] "s"(total_elems), [w2lo] "s"(w2_lo), [soft] "v"(softening), [c15] "v"(c15),
-              [pxA] "v"(pxa), [pyA] "v"(pya), [th2] "s"(theta2), [one] "s"(one)
-            : PSIM_WALK_CLOBBERS_A);
-    }
+    [[maybe_unused]] double scale;
+    [[maybe_unused]] const double one = 1.0;
+    [[maybe_unused]] const uint32_t rec_lo = (uint32_t)reinterpret_cast<uintptr_t>(rec4);
+    [[maybe_unused]] const uint32_t rec_hi = (uint32_t)(reinterpret_cast<uintptr_t>(rec4) >> 32);
+    if constexpr (FOLD && !WIDE) PSIM_WALK_ASM_ONE(FOLDED, NARROW);
+    else if constexpr (FOLD) PSIM_WALK_ASM_ONE(FOLDED, WIDE);
+    else if constexpr (!WIDE) PSIM_WALK_ASM_ONE(SCALED, NARROW);
+    else PSIM_WALK_ASM_ONE(SCALED, WIDE);
 }
+#undef PSIM_WALK_ASM_ONE
+#undef PSIM_WALK_ASM_TWO
+#undef PSIM_WALK_IN_NARROW
+#undef PSIM_WALK_IN_WIDE
+#undef PSIM_WALK_CLOB_NARROW
+#undef PSIM_WALK_CLOB_WIDE
+#undef PSIM_WALK_IN_FOLDED
+#undef PSIM_WALK_IN_SCALED
+#undef PSIM_WALK_OUT_FOLDED
+#undef PSIM_WALK_OUT_SCALED
+#undef PSIM_WALK_FETCH_NARROW
+#undef PSIM_WALK_FETCH_WIDE
 #undef PSIM_WALK_CLOBBERS_A
 #undef PSIM_WALK_CLOBBERS_B
 #undef PSIM_WALK_ONE
@@ -1181,7 +1205,7 @@ __device__ __forceinline__ void walk_one_group_loop(const double4_t* rec4, uint3
 // pointer arguments, for a velocity kick fused into the epilogue) left those kernels 1.5x
 // slower under the walk (tools/kernel_resources.py lists what every kernel allocates).
 // amdgpu_num_sgpr(80) holds every variant at the 80-register allocation step.
-// HAND (two groups, 32-bit offsets only): the two-group loop and the one-group
+// HAND (two groups): the two-group loop and the one-group
 // tails are the hand-scheduled ones above (walk_two_groups_loop, walk_one_group_loop) instead
 // of the compiler's.
 template <int K, bool FOLD, bool WIDE, bool HAND = false>
@@ -1265,7 +1289,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) gravi
         const bool descend = !leaf && (__builtin_amdgcn_ballot_w64(untilk <= ju) != 0ull);
         return descend ? ja : jb;
     };
-    if (!WIDE) {
+    if (!WIDE || HAND) {
         // the kernel arguments the loop reads are pinned into registers here, so that the
         // compiler places no scalar-load wait of its own between the requests and their use
         asm volatile("" : "+s"(w2_lo), "+s"(theta2), "+s"(softening), "+s"(total_elems));
@@ -1273,10 +1297,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) gravi
             static_assert(K == 2, "the hand-scheduled loop is the two-group one");
             // (three groups per wave with the same loop were measured: no faster alone, and the
             // 90 scalar registers they need leave the side stream's kernels fewer waves)
-            walk_two_groups_loop<FOLD>(rec4, j[0], j[1], total_elems, w2_lo, theta2, softening, px[0], py[0], px[1], py[1],
-                                       ax[0], ay[0], ax[1], ay[1], until[0], until[1]);
-            walk_one_group_loop<FOLD>(rec4, j[0], total_elems, w2_lo, theta2, softening, px[0], py[0], ax[0], ay[0], until[0]);
-            walk_one_group_loop<FOLD>(rec4, j[1], total_elems, w2_lo, theta2, softening, px[1], py[1], ax[1], ay[1], until[1]);
+            walk_two_groups_loop<FOLD, WIDE>(rec4, j[0], j[1], total_elems, w2_lo, theta2, softening, px[0], py[0], px[1],
+                                             py[1], ax[0], ay[0], ax[1], ay[1], until[0], until[1]);
+            walk_one_group_loop<FOLD, WIDE>(rec4, j[0], total_elems, w2_lo, theta2, softening, px[0], py[0], ax[0], ay[0],
+                                            until[0]);
+            walk_one_group_loop<FOLD, WIDE>(rec4, j[1], total_elems, w2_lo, theta2, softening, px[1], py[1], ax[1], ay[1],
+                                            until[1]);
         } else
         for (;;) {
             bool all = true;
@@ -1340,24 +1366,20 @@ inline void launch_walk_multi(Stream st, int64_t lo, int64_t hi, int sorted_out,
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(64), 0, st, lo, hi, sorted_out, rec, total, spos, smass,
                            perm, order, out, w2_lo, theta2, g_const, softening, (uint32_t)chunks, chunk_counter);
     };
-    if (fold && !wide) {
+    // (K == 2: the hand-scheduled loops unless the compiler's are asked for)
+    auto pick = [&](auto fold_c, auto wide_c) {
+        constexpr bool F = decltype(fold_c)::value, W = decltype(wide_c)::value;
         if constexpr (K == 2) {
-            if (!compiler_loop) go(gravity_walk_multi_kernel<2, true, false, true>);
-            else go(gravity_walk_multi_kernel<2, true, false>);
+            if (!compiler_loop) go(gravity_walk_multi_kernel<2, F, W, true>);
+            else go(gravity_walk_multi_kernel<2, F, W>);
         } else {
-            go(gravity_walk_multi_kernel<K, true, false>);
+            go(gravity_walk_multi_kernel<K, F, W>);
         }
-    }
-    else if (fold) go(gravity_walk_multi_kernel<K, true, true>);
-    else if (!wide) {
-        if constexpr (K == 2) {
-            if (!compiler_loop) go(gravity_walk_multi_kernel<2, false, false, true>);
-            else go(gravity_walk_multi_kernel<2, false, false>);
-        } else {
-            go(gravity_walk_multi_kernel<K, false, false>);
-        }
-    }
-    else go(gravity_walk_multi_kernel<K, false, true>);
+    };
+    if (fold && !wide) pick(std::true_type(), std::false_type());
+    else if (fold) pick(std::true_type(), std::true_type());
+    else if (!wide) pick(std::false_type(), std::false_type());
+    else pick(std::false_type(), std::true_type());
     PSIM_HIP(hipGetLastError());
 }
 

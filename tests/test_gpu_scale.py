@@ -177,12 +177,14 @@ def test_first_step_contact_outputs_bit_exact_without_priming():
                               min_contacts=20000)
 
 
-@pytest.mark.parametrize("wide,narrow,theta", [(3, 0, 0.5), (4, 2, 0.5), (5, 0, 0.5), (5, 0, 0.7), (3, 0, 0.3)])
+@pytest.mark.parametrize("wide,narrow,theta", [(3, 0, 0.5), (4, 2, 0.5), (5, 0, 0.5), (5, 0, 0.7), (3, 0, 0.3), (3, 5, 0.5),
+                                               (3, 5, 0.7)])
 def test_wide_offset_walk_equals_narrow(wide, narrow, theta):
     """the walk kernels' 64-bit element offsets (taken for trees of 4 GiB and more, 2^27
     elements) forced on at a small size: bit-identical accelerations and states.  (5, 0): the
     default walk's hand-scheduled loop against the same kernel with the compiler's loop, with
-    theta^2 a power of two (folded into the elements' tags) and not (scaled acceptance test)."""
+    theta^2 a power of two (folded into the elements' tags) and not (scaled acceptance test);
+    (3, 5): the hand-scheduled loop with 64-bit offsets against the compiler's with 32-bit ones."""
     n, bounds = 300000, (24000, 12500)
     sim = dict(SIM, barnes_hut_theta=theta)
     a = ParticleSystem(n, dict(sim), np.random.default_rng(5), bounds, walk_mode=narrow)
