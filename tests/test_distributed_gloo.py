@@ -27,7 +27,8 @@ def run_ranks(world, backend, library, name, steps, timeout=240):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   DIST_WORKER_DUMP_AFTER=str(max(10, int(timeout) - 20)))     # (a stuck rank says where before it is killed)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), backend, library,
                                        name, str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
