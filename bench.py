@@ -166,6 +166,13 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
 
+    # A sharded rank uses more streams than HIP's default of four hardware queues per process
+    # (the library's two, the exchange stream, the collective library's own): streams that
+    # share a queue wait for one another's barriers.  Read by the HIP runtime when it starts,
+    # which is after this line.
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
     # stdout carries exactly one JSON line: libraries that print there (RCCL announces its
     # version on stdout when a communicator is created) are sent to stderr instead
     sys.stdout.flush()
