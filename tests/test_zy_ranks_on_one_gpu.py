@@ -9,7 +9,7 @@ from test_distributed_gloo import run_ranks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,name,steps", [(2, "dense256", 6), (3, "hot300", 6), (2, "c4:300000", 3), (4, "c4:150000", 3)])
+@pytest.mark.parametrize("world,name,steps", [(2, "dense256", 6), (3, "hot300", 6), (2, "c4:300000", 3)])
 def test_sharded_over_several_ranks_on_the_hip_library(world, name, steps):
     """every rank checks, step by step, that the sharded state is bit-identical to its own
     unsharded run: target ranges of the walk that start inside the sorted array, detection
