@@ -166,13 +166,6 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
 
-    # A sharded rank uses more streams than HIP's default of four hardware queues per process
-    # (the library's two, the exchange stream, the collective library's own): streams that
-    # share a queue wait for one another's barriers.  Read by the HIP runtime when it starts,
-    # which is after this line.
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
-        os.environ["GPU_MAX_HW_QUEUES"] = "8"       # (the variable may be there already, set to HIP's default)
-
     # stdout carries exactly one JSON line: libraries that print there (RCCL announces its
     # version on stdout when a communicator is created) are sent to stderr instead
     sys.stdout.flush()

@@ -73,6 +73,9 @@ inline Event event_create()
 inline void event_destroy(Event e) { if (e) (void)hipEventDestroy(e); }
 inline void event_record(Event e, Stream s) { PSIM_HIP(hipEventRecord(e, s)); }
 inline void stream_wait(Stream s, Event e) { PSIM_HIP(hipStreamWaitEvent(s, e, 0)); }
+// one turn of a host-side polling loop: lets the core's other thread and the HIP runtime's
+// own threads (whose lock an event query takes) have the cycles
+inline void cpu_relax() { __builtin_ia32_pause(); }
 // has everything submitted before the event's record finished? (no waiting)
 inline bool event_done(Event e)
 {
@@ -143,6 +146,7 @@ inline void mailbox_fetch(Stream st, Mailbox& m, void* dst, const void* a, uint3
             PSIM_HIP(hipStreamSynchronize(st));
             if (m.host[Mailbox::kWords] != seq) throw std::runtime_error("mailbox_fetch: readback did not arrive");
         }
+        cpu_relax();
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     memcpy(dst, (const void*)m.host, (size_t)(na + nb) * 4);

@@ -1368,7 +1368,7 @@ public:
             // The host has nothing to submit before the walk ends.  If the side work ends first
             // (the usual case) the main stream needs no wait packet for it, which otherwise
             // sits between the kick and the velocity half for some 25 us.
-            while (walk_in_flight && !be::event_done(ev_side) && !be::event_done(ev_walk())) {}
+            while (walk_in_flight && !be::event_done(ev_side) && !be::event_done(ev_walk())) be::cpu_relax();
             if (!be::event_done(ev_side)) be::stream_wait(st, ev_side);
         }
         side_running = false;

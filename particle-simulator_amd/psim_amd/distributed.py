@@ -24,8 +24,6 @@ Each element is computed by exactly one rank with the same arithmetic as the
 single-GPU step, so the result is bit-identical for any number of ranks.
 """
 import ctypes
-import os
-import warnings
 
 import numpy as np
 import torch
@@ -56,11 +54,6 @@ class ShardedParticleSystem(ParticleSystem):
         self._group = group
         self._rank = dist.get_rank(group)
         self._world = dist.get_world_size(group)
-        if self._world > 1 and kw.get("library") is None and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
-            # (HIP reads the variable when its runtime starts, so it is too late to set it here)
-            warnings.warn("psim: a sharded rank uses more streams than HIP's default of four hardware queues per "
-                          "process, and streams that share a queue wait for each other's barriers; start the ranks "
-                          "with GPU_MAX_HW_QUEUES=8", RuntimeWarning, stacklevel=2)
         on_gpu = kw.get("library") is None
         self._tdev = torch.device("cuda", self._device) if on_gpu else torch.device("cpu")
         n = self.num_particles

@@ -36,6 +36,7 @@ inline void event_record(Event, Stream) {}
 inline void stream_wait(Stream, Event) {}
 inline void delay(Stream, uint32_t) {}
 inline bool event_done(Event) { return true; }
+inline void cpu_relax() {}
 inline void* host_alloc_pinned(size_t bytes) { return calloc(bytes ? bytes : 16, 1); }
 inline void host_free_pinned(void* p) { free(p); }
 

@@ -29,10 +29,6 @@ def run_ranks(world, backend, library, name, steps, timeout=240):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
                    DIST_WORKER_DUMP_AFTER=str(max(10, int(timeout) - 20)))     # (a stuck rank says where before it is killed)
-        # (a sharded rank has more streams than HIP's default four hardware queues per process;
-        # streams sharing a queue wait for one another's barriers: seconds per step at four ranks)
-        if int(env.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
-            env["GPU_MAX_HW_QUEUES"] = "8"          # (the variable may be there already, set to HIP's default)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), backend, library,
                                        name, str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
