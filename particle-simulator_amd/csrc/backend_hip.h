@@ -1013,7 +1013,8 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 //   as fetch offset and as skip target: the kernel has to stay within 80 scalar registers,
 //   or the side stream's kernels lose the wave slots beside it.
 // v_rsq_f64 is followed by an independent instruction before its result is read, as the
-// compiler's schedule has it.
+// compiler's schedule has it.  (Labels end in "_%=": the assembler numbers the copies of a
+// block, and without the separator label `a` of copy 20 is label `a2` of copy 0.)
 #define PSIM_WALK_GROUP(ACCEPT, M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                 \
     "v_add_f64 %[dy], " Y ", -%[" PY "]\n"                                                              \
     "v_add_f64 %[dx], " X ", -%[" PX "]\n"                                                              \
@@ -1025,7 +1026,7 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     "v_cmp_ge_u32 vcc, %[" CUR "], %[" UNTIL "]\n"                                                      \
     ACCEPT(LHS)                                                                                         \
     "s_and_b64 %[take], vcc, %[take]\n"                                                                 \
-    "s_cbranch_scc0 .Lpsim_walk_" L "%=\n"                                                              \
+    "s_cbranch_scc0 .Lpsim_walk_" L "_%=\n"                                                              \
     "s_mov_b64 exec, %[take]\n"                                                                         \
     "v_add_f64 %[d2], %[soft], %[d2]\n"                                                                 \
     "v_rsq_f64 %[y], %[d2]\n"                                                                           \
@@ -1039,7 +1040,7 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     "v_fmac_f64 %[" AX "], %[d2], %[dx]\n"                                                              \
     "v_fmac_f64 %[" AY "], %[d2], %[dy]\n"                                                              \
     "s_mov_b64 exec, -1\n"                                                                              \
-    ".Lpsim_walk_" L "%=:\n"                                                                            \
+    ".Lpsim_walk_" L "_%=:\n"                                                                            \
     "s_andn2_b64 vcc, vcc, %[take]\n"                                                                   \
     "s_cselect_b32 %[" CUR "], %[ja], %[jb]\n"
 // The acceptance test.  Folded (theta^2 a power of two, divided into the elements' tags): lhs < d^2.
@@ -1053,12 +1054,12 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 // the element fetched along, when the cursor has moved onto it and it exists
 #define PSIM_WALK_SECOND(ACCEPT, M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                \
     "s_cmp_lg_u32 %[" CUR "], %[ja]\n"                                                                  \
-    "s_cbranch_scc1 .Lpsim_walk_done_" L "%=\n"                                                         \
+    "s_cbranch_scc1 .Lpsim_walk_done_" L "_%=\n"                                                         \
     "s_cmp_ge_u32 %[" CUR "], %[tot]\n"                                                                 \
-    "s_cbranch_scc1 .Lpsim_walk_done_" L "%=\n"                                                         \
+    "s_cbranch_scc1 .Lpsim_walk_done_" L "_%=\n"                                                         \
     "s_add_i32 %[ja], %[" CUR "], 1\n"                                                                  \
     PSIM_WALK_GROUP(ACCEPT, M, X, Y, SKIP, TAG, LHS, PX, PY, AX, AY, UNTIL, CUR, L)                     \
-    ".Lpsim_walk_done_" L "%=:\n"
+    ".Lpsim_walk_done_" L "_%=:\n"
 #define PSIM_WALK_A1(ACC) PSIM_WALK_GROUP(ACC, "s[40:41]", "s[42:43]", "s[44:45]", "s46", "s47", "s[46:47]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a")
 #define PSIM_WALK_A2(ACC) PSIM_WALK_SECOND(ACC, "s[48:49]", "s[50:51]", "s[52:53]", "s54", "s55", "s[54:55]", "pxA", "pyA", "axA", "ayA", "uA", "jA", "a2")
 #define PSIM_WALK_B1(ACC) PSIM_WALK_GROUP(ACC, "s[56:57]", "s[58:59]", "s[60:61]", "s62", "s63", "s[62:63]", "pxB", "pyB", "axB", "ayB", "uB", "jB", "b")
@@ -1077,8 +1078,8 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
 #define PSIM_WALK_TWO(ACC, FETCH)                                                                        \
         "s_max_u32 %[jb], %[jA], %[jB]\n"                                                               \
         "s_cmp_lt_u32 %[jb], %[tot]\n"                                                                  \
-        "s_cbranch_scc0 .Lpsim_walk_end%=\n"                                                            \
-        ".Lpsim_walk_loop%=:\n"                                                                         \
+        "s_cbranch_scc0 .Lpsim_walk_end_%=\n"                                                            \
+        ".Lpsim_walk_loop_%=:\n"                                                                         \
         FETCH("s[40:55]", "jA")                                                                         \
         FETCH("s[56:71]", "jB")                                                                         \
         "s_add_i32 %[ja], %[jA], 1\n"                                                                   \
@@ -1090,20 +1091,20 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
         PSIM_WALK_B2(ACC)                                                                               \
         "s_max_u32 %[jb], %[jA], %[jB]\n"                                                               \
         "s_cmp_lt_u32 %[jb], %[tot]\n"                                                                  \
-        "s_cbranch_scc1 .Lpsim_walk_loop%=\n"                                                           \
-        ".Lpsim_walk_end%=:\n"
+        "s_cbranch_scc1 .Lpsim_walk_loop_%=\n"                                                           \
+        ".Lpsim_walk_end_%=:\n"
 #define PSIM_WALK_ONE(ACC, FETCH)                                                                        \
         "s_cmp_lt_u32 %[jA], %[tot]\n"                                                                  \
-        "s_cbranch_scc0 .Lpsim_walk_end%=\n"                                                            \
-        ".Lpsim_walk_loop%=:\n"                                                                         \
+        "s_cbranch_scc0 .Lpsim_walk_end_%=\n"                                                            \
+        ".Lpsim_walk_loop_%=:\n"                                                                         \
         FETCH("s[40:55]", "jA")                                                                         \
         "s_add_i32 %[ja], %[jA], 1\n"                                                                   \
         "s_waitcnt lgkmcnt(0)\n"                                                                        \
         PSIM_WALK_A1(ACC)                                                                               \
         PSIM_WALK_A2(ACC)                                                                               \
         "s_cmp_lt_u32 %[jA], %[tot]\n"                                                                  \
-        "s_cbranch_scc1 .Lpsim_walk_loop%=\n"                                                           \
-        ".Lpsim_walk_end%=:\n"
+        "s_cbranch_scc1 .Lpsim_walk_loop_%=\n"                                                           \
+        ".Lpsim_walk_end_%=:\n"
 #define PSIM_WALK_CLOBBERS_A "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
 #define PSIM_WALK_CLOBBERS_B "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
 
