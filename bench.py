@@ -154,6 +154,11 @@ def main():
                          "one-GPU box; the ranks share the device, so the timings mean nothing)")
     ap.add_argument("--staged", action="store_true",
                     help="drive the step through the psim_stage_* entry points (the multi-GPU path) even on one GPU")
+    ap.add_argument("--emulate-rank", type=int, default=None,
+                    help="with --staged --world W: ONE process on one GPU plays all W ranks of the sharded step in turn and "
+                         "times the share of this rank alone (what one GPU of a W-GPU job computes per step, and the bytes "
+                         "it exchanges); the other ranks' shares are computed untimed so that the state stays exact")
+    ap.add_argument("--world", type=int, default=8, help="number of ranks played with --emulate-rank")
     ap.add_argument("--no-overlap", action="store_true",
                     help="every stage on one stream (kernel timings without the side stream's contention)")
     ap.add_argument("--brute", type=int, default=262144,
@@ -182,7 +187,13 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
         torch.cuda.set_device(local_rank)
-    if world > 1 or args.staged:
+    emulate = None
+    if args.emulate_rank is not None:
+        if world != 1:
+            raise SystemExit("--emulate-rank plays the ranks in one process: use it with --gpus 1")
+        emulate = (args.world, args.emulate_rank)
+        args.staged = True
+    if (world > 1 or args.staged) and emulate is None:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:
@@ -200,17 +211,18 @@ def main():
     # N > 1: C3 (16Mi rotating disk), ONE simulation sharded over the N ranks: every
     # rank holds the state, gravity is split by sorted-target range, contact detection and
     # conduction by grid-slot range, outputs all-gathered over RCCL (psim_amd/distributed.py).
-    wl = args.workload or ("c2" if world == 1 else "c3")
+    wl = args.workload or ("c2" if world == 1 and emulate is None else "c3")
     label, n, bounds, state, mask = workload(wl)
     if world > 1 or args.staged:
         from psim_amd.distributed import ShardedParticleSystem
         ps = ShardedParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds, device=local_rank,
-                                   stage_mask=mask, walk_mode=args.walk_mode, state=state, library=args.library)
+                                   stage_mask=mask, walk_mode=args.walk_mode, state=state, library=args.library,
+                                   emulate=emulate)
     else:
         ps = ParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds, device=local_rank,
                             stage_mask=mask, walk_mode=args.walk_mode, state=state, library=args.library,
                             overlap=not args.no_overlap)
-    want_cpu = not args.no_cpu_baseline and world == 1 and rank == 0
+    want_cpu = not args.no_cpu_baseline and world == 1 and rank == 0 and emulate is None
     initial = None
     if want_cpu:
         initial = dict(positions=ps.positions.copy(), masses=ps.masses.copy(), temperatures=ps.temperatures.copy(),
@@ -219,6 +231,8 @@ def main():
     primed = ps.accelerations.copy() if want_cpu else None
     for _ in range(args.warmup):
         ps.update()
+    if emulate is not None:
+        ps.emulated_ms = {}
 
     def barrier():
         if on_gpu:
@@ -240,6 +254,24 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     steps = max(args.steps, 1)
+    emulated = None
+    if emulate is not None:
+        # the rank's own share: the sum of its timed pieces (host clock, device idle at both
+        # ends of every piece); the other ranks' pieces, computed in between, are not in it
+        pieces = {k: v / steps for k, v in ps.emulated_ms.items()}
+        dt = sum(ps.emulated_ms.values()) * 1e-3
+        link_gbs = 153.0
+        xb = dict(ps.exchange_bytes)
+        W = emulate[0]
+        # all-gather over the 7 direct xGMI links of a GPU: every rank receives W - 1 shards, one per link
+        xb["accelerations_received"] = xb["accelerations_per_rank"] * (W - 1)
+        xb["blocks_received"] = xb["block_sent_per_rank"] * (W - 1)
+        emulated = {"world": W, "rank": emulate[1], "ms_per_step_by_piece": pieces, "exchange_bytes": xb,
+                    "exchange_ms_at_link_rate": {"accelerations": xb["accelerations_per_rank"] / (link_gbs * 1e6),
+                                                 "blocks": xb["block_sent_per_rank"] / (link_gbs * 1e6),
+                                                 "assumed_GB_per_s_per_link": link_gbs},
+                    "rows": ps._row_bounds, "fallbacks": ps.fallbacks,
+                    "note": "ms_per_step and value are this rank's compute share only (exchanges excluded)"}
     stage_ms = {k: v / steps for k, v in stage_acc.items()}
     walk_ms_ranks = [stage_ms.get("gravity", 0.0)]
     if world > 1:
@@ -257,17 +289,17 @@ def main():
         # visits summed over particles, both counted on the current tree.
         visits, inter = ps.walk_counts()
         flops = 20.0 * inter + 8.0 * (visits - inter)
-        if world > 1:
+        if world > 1 or emulate is not None:
             # a rank's launch walks 1/world of the (Morton-sorted) targets: per-GPU figure,
             # taking the ranks' shares of the work as equal
-            flops /= world
+            flops /= (emulate[0] if emulate is not None else world)
         walk_ms = max(walk_ms_ranks)
         achieved = flops / (walk_ms * 1e-3) / 1e12 if walk_ms > 0 else 0.0
         counts = ps.counts()
         # In the step the walk shares the device: it holds part of the wave slots and the
         # grid build and contact solver run in the rest.  The same kernel on the same tree
         # with the device to itself, for comparison:
-        alone_ms = ps.time_walk(3, 0.0) if (world == 1 and on_gpu) else None
+        alone_ms = ps.time_walk(3, 0.0) if (world == 1 and on_gpu and emulate is None) else None
         out = {
             "metric": "particle-updates/sec", "value": updates / dt, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -277,7 +309,9 @@ def main():
             "config": {"workload": label, "particles": n, "theta": SIM["barnes_hut_theta"],
                        "multi_gpu": ("one simulation sharded over %d ranks: walk by sorted-target range, contact detection "
                                      "and conduction by grid-slot slabs, RCCL all-gathers" % world) if world > 1 else
-                                     ("single (stage entry points of the sharded path, one rank)" if args.staged else "single")},
+                                     ("rank %d of %d played by one process (its compute share only)" % (emulate[1], emulate[0])
+                                      if emulate is not None else
+                                      "single (stage entry points of the sharded path, one rank)" if args.staged else "single")},
             "roofline": {"kernel": "gravity_walk_multi_kernel", "bound": "valu", "achieved": achieved,
                          "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": None,
@@ -294,6 +328,9 @@ def main():
                           "solver_rounds": counts["solver_rounds"], "tree_nodes": counts["tree_nodes"],
                           "particles": counts["particles"]},
         }
+        if emulated is not None:
+            out["emulated_rank"] = emulated
+            out["roofline"]["note"] = "walk kernel time is not separated in this mode (see ms_per_step_by_piece)"
         if world > 1:
             out["roofline"]["kernel_ms_per_rank"] = walk_ms_ranks
             out["roofline"]["frac_per_rank"] = [flops / (m * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if m > 0 else 0.0
@@ -301,7 +338,7 @@ def main():
         if alone_ms:
             tf = flops / (alone_ms * 1e-3) / 1e12
             out["roofline"]["device_to_itself"] = {"kernel_ms": alone_ms, "achieved": tf, "frac": tf / PEAK_FP64_VALU_TFLOPS}
-        if args.brute and on_gpu and world == 1:
+        if args.brute and on_gpu and world == 1 and emulate is None:
             # yardstick: the same force arithmetic with no tree and no divergence
             nb = args.brute
             side = float(np.sqrt(nb / 1e-3))
@@ -318,7 +355,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, bounds, initial, primed, mask, label)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if world > 1 or args.staged:
+    if (world > 1 or args.staged) and emulate is None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -98,54 +98,60 @@ int psim_prime_gravity(psim_context* ctx);
 /* replaces: ParticleSystem.update() called k_steps times (particle_system.py:518-563) */
 int psim_step(psim_context* ctx, int64_t k_steps);
 
-/* One simulation sharded over several GPUs (no counterpart in the reference, which
- * is single-process): psim_step cut at its two exchange points.  Every rank holds
- * the full state and calls all five in order; between them the caller all-gathers
- * the device buffers (RCCL):
- *   psim_stage_build         drift, grid, tree (identical on every rank)
- *   psim_stage_gravity       walk for the sorted particles [s_lo, s_hi) -> acc_sorted[s]
- *                            (device pointer, (n,2) float64, indexed by sorted position).
- *                            Returns once the walk is submitted to the context's stream (the
- *                            device's default stream): an exchange submitted to that stream,
- *                            or to one that waits for it, is ordered after the walk.
+/* One simulation split over several GPUs (no counterpart in the reference, which is
+ * single-process): psim_step cut at its exchange points.  Every rank holds the full state
+ * and builds the same tree.  The walk runs on a rank's share of the Morton-sorted
+ * particles.  The collision stage and conduction (particle_system.py:439-498) run on bands
+ * of whole grid rows: cells are row-major (particle_system.py:749), so a band is a slab of
+ * the domain; a rank solves the rows it owns plus halo rows on a grid of that band only and
+ * exports the results of its own rows; along every seam both ranks also export the contacts
+ * they saw in the two rows next to it, and the results are applied only when those records
+ * are identical (each rank's view of its neighbour's rows was then the true one, and the
+ * owned results together are exactly the sequential sweep's).  Otherwise the step's
+ * collision stage is run again on the whole grid by every rank.  Calls, in order:
+ *   psim_stage_build          drift, Morton keys, tree (identical on every rank)
+ *   psim_stage_gravity        walk for the sorted particles [s_lo, s_hi) -> acc_sorted[s]
+ *                             (device pointer, (n,2) float64, indexed by sorted position).
+ *                             Returns once the walk is submitted to the context's stream (the
+ *                             device's default stream): an exchange submitted to that stream,
+ *                             or to one that waits for it, is ordered after the walk.
  *   -- all-gather acc_sorted (may be started asynchronously) --
- *   psim_stage_detect        optional: contact detection of the first sweep for the grid
- *                            slots [k_lo, k_hi) only (k_lo a multiple of 4) -> keys_out (device
- *                            pointer, room for `cap` 64-bit keys).  Cells are row-major, so a
- *                            range of slots is a slab of the domain; every rank holds all
- *                            positions, so a slab needs no halo.  out[0] contacts found in the
- *                            range, out[1] candidate pairs examined (counted in debug builds of
- *                            the configuration only), out[2] pairs at squared distance zero,
- *                            out[3] keys written (0 when cap < out[0]: call again with room).
- *   -- all-gather the key lists --
- *   psim_stage_settle_positions_from  as psim_stage_settle_positions, but on the gathered list
- *                            (device pointer, n_keys keys in any order) instead of a sweep
- *                            over all slots; candidates / coincident are the sums of out[1] /
- *                            out[2] over the ranks
- *   psim_stage_settle_positions  optional: the half of the contact solver that needs no
- *                            velocities (contact list, pushed-apart positions), on the
- *                            library's second stream while the exchange is in flight;
- *                            psim_stage_kick_collide does it itself if this was not called
- *   psim_stage_kick_collide  kick from the gathered accelerations; rest of the contact solver
- *   psim_stage_conduction    conduction + cooling for grid slots [k_lo, k_hi) ->
- *                            temp_slots[k] (device pointer, (n) float64, slot order)
- *   -- all-gather temp_slots --
- *   psim_stage_finish        temperatures back to particle order; walls; explosions
- * Results are bit-identical to psim_step for any split of the ranges. */
+ *   psim_stage_slab_positions grid of the rows [row_lo, row_hi), contact list and pushed-apart
+ *                             positions of that band ([own_lo, own_hi) = the rows whose results
+ *                             this rank keeps; the rest is halo).  On the library's second
+ *                             stream while a walk is in flight.
+ *   psim_stage_kick           second half-kick from the gathered accelerations
+ *   psim_stage_slab_finish    velocity half of the band's contacts, conduction sums
+ *   psim_stage_slab_export    the band's block of 64-bit words into `block` (device pointer, room
+ *                             for cap_words): header, state of the touched particles of the own
+ *                             rows, conduction sums of the own rows, seam records.
+ *                             *words_needed > cap_words: only the header was written; call again
+ *                             with room (any number of times before the next band or step).
+ *   -- all-gather the blocks (equal size on every rank) --
+ *   psim_stage_apply          blocks = `world` blocks of block_words words in rank order (device
+ *                             pointer).  *status 0: seams agree, all results applied.  1: a seam
+ *                             disagrees, nothing applied: call psim_stage_fallback.  2: a block was
+ *                             incomplete (*words_needed = the largest need): export again, gather
+ *                             again, call again.  own_slots (may be NULL): [world] particles in
+ *                             each rank's own rows, for balancing the next step's bands.
+ *   psim_stage_fallback       the whole collision stage on the whole grid (every rank alike)
+ *   psim_stage_finish         conduction applied, cooling, walls, explosions
+ * Results are bit-identical to psim_step for any number of ranks and any bands that tile the
+ * grid rows (halo >= 2 rows on either side of the own rows, clipped to the grid), except the
+ * three collision totals, which are sums of the ranks' partial sums.
+ * psim_stage_stats: [0] steps that took the fallback so far, [1] particles in the own rows of
+ * the last band, [2] particles in the last band, [3] words of a block's header. */
 int psim_stage_build(psim_context* ctx);
 int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* acc_sorted);
-int psim_stage_settle_positions(psim_context* ctx);
-int psim_stage_detect(psim_context* ctx, int64_t k_lo, int64_t k_hi, uint64_t* keys_out, int64_t cap, int64_t out[4]);
-int psim_stage_settle_positions_from(psim_context* ctx, const uint64_t* keys, int64_t n_keys, int64_t candidates,
-                                     int64_t coincident);
-int psim_stage_kick_collide(psim_context* ctx, const double* acc_sorted);
-int psim_stage_conduction(psim_context* ctx, int64_t k_lo, int64_t k_hi, double* temp_slots);
-int psim_stage_finish(psim_context* ctx, const double* temp_slots);
-/* after psim_stage_kick_collide: *out = 1 when this step's conduction needs the exchange of
- * temp_slots (full sweep split by slot range), 0 when every rank does all of it locally
- * (sweep around the slots the contacts touched) and the all-gather can be skipped.  The
- * answer depends on the state only, so it is the same on every rank. */
-int psim_stage_conduction_exchanges(psim_context* ctx, int32_t* out);
+int psim_stage_slab_positions(psim_context* ctx, int32_t row_lo, int32_t row_hi, int32_t own_lo, int32_t own_hi);
+int psim_stage_kick(psim_context* ctx, const double* acc_sorted);
+int psim_stage_slab_finish(psim_context* ctx);
+int psim_stage_slab_export(psim_context* ctx, uint64_t* block, int64_t cap_words, int64_t* words_needed);
+int psim_stage_apply(psim_context* ctx, const uint64_t* blocks, int32_t world, int64_t block_words, int32_t* status,
+                     int64_t* own_slots, int64_t* words_needed);
+int psim_stage_fallback(psim_context* ctx);
+int psim_stage_finish(psim_context* ctx);
+int psim_stage_stats(psim_context* ctx, int64_t out[4]);
 
 /* replaces: get_total_kinetic_energy / get_total_potential_energy /
  * get_total_thermal_energy (particle_system.py:765-804); out[0..2] = KE, PE, TE,

@@ -236,64 +236,71 @@ int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* ac
     })
 }
 
-int psim_stage_settle_positions(psim_context* ctx)
+int psim_stage_slab_positions(psim_context* ctx, int32_t row_lo, int32_t row_hi, int32_t own_lo, int32_t own_hi)
 {
     PSIM_TRY(ctx, {
         use_device(ctx->device);
-        ctx->sim->stage_settle_positions();
+        ctx->sim->stage_slab_positions(psim::Sim::Band{row_lo, row_hi, own_lo, own_hi});
     })
 }
 
-int psim_stage_detect(psim_context* ctx, int64_t k_lo, int64_t k_hi, uint64_t* keys_out, int64_t cap, int64_t out[4])
-{
-    PSIM_TRY(ctx && out && (keys_out || cap == 0) && cap >= 0, {
-        use_device(ctx->device);
-        ctx->sim->stage_detect(k_lo, k_hi, keys_out, cap, out);
-    })
-}
-
-int psim_stage_settle_positions_from(psim_context* ctx, const uint64_t* keys, int64_t n_keys, int64_t candidates,
-                                     int64_t coincident)
-{
-    PSIM_TRY(ctx, {
-        use_device(ctx->device);
-        ctx->sim->stage_settle_positions_from(keys, n_keys, candidates, coincident);
-    })
-}
-
-int psim_stage_kick_collide(psim_context* ctx, const double* acc_sorted)
+int psim_stage_kick(psim_context* ctx, const double* acc_sorted)
 {
     PSIM_TRY(ctx && acc_sorted, {
         use_device(ctx->device);
-        ctx->sim->stage_kick_collide(reinterpret_cast<const psim::vec2*>(acc_sorted));
-        psim::be::sync(ctx->sim->st);
+        ctx->sim->stage_kick(reinterpret_cast<const psim::vec2*>(acc_sorted));
     })
 }
 
-int psim_stage_conduction(psim_context* ctx, int64_t k_lo, int64_t k_hi, double* temp_slots)
+int psim_stage_slab_finish(psim_context* ctx)
 {
-    PSIM_TRY(ctx && temp_slots, {
+    PSIM_TRY(ctx, {
         use_device(ctx->device);
-        ctx->sim->stage_conduction(k_lo, k_hi, temp_slots);
+        ctx->sim->stage_slab_finish();
+    })
+}
+
+int psim_stage_slab_export(psim_context* ctx, uint64_t* block, int64_t cap_words, int64_t* words_needed)
+{
+    PSIM_TRY(ctx && block && words_needed, {
+        use_device(ctx->device);
+        *words_needed = ctx->sim->slab_export(block, cap_words);
+    })
+}
+
+int psim_stage_apply(psim_context* ctx, const uint64_t* blocks, int32_t world, int64_t block_words, int32_t* status,
+                     int64_t* own_slots, int64_t* words_needed)
+{
+    PSIM_TRY(ctx && blocks && status, {
+        use_device(ctx->device);
+        *status = ctx->sim->stage_apply(blocks, world, block_words, own_slots, words_needed);
+    })
+}
+
+int psim_stage_fallback(psim_context* ctx)
+{
+    PSIM_TRY(ctx, {
+        use_device(ctx->device);
+        ctx->sim->stage_fallback();
+    })
+}
+
+int psim_stage_finish(psim_context* ctx)
+{
+    PSIM_TRY(ctx, {
+        use_device(ctx->device);
+        ctx->sim->stage_finish();
         psim::be::sync(ctx->sim->st);
     })
 }
 
-int psim_stage_conduction_exchanges(psim_context* ctx, int32_t* out)
+int psim_stage_stats(psim_context* ctx, int64_t out[4])
 {
     PSIM_TRY(ctx && out, {
-        psim::Sim* s = ctx->sim;
-        bool cond = (s->cfg.stage_mask & psim::kStageConduction) != 0;
-        *out = (cond && s->n > 0 && !s->sparse_conduction_possible()) ? 1 : 0;
-    })
-}
-
-int psim_stage_finish(psim_context* ctx, const double* temp_slots)
-{
-    PSIM_TRY(ctx && temp_slots, {
-        use_device(ctx->device);
-        ctx->sim->stage_finish(temp_slots);
-        psim::be::sync(ctx->sim->st);
+        out[0] = ctx->sim->slab_fallbacks;
+        out[1] = ctx->sim->own_slots;
+        out[2] = ctx->sim->ns;
+        out[3] = psim::kExportHeaderWords;
     })
 }
 

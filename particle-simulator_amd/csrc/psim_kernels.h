@@ -252,15 +252,48 @@ struct GatherCell {
     const PackedBody* pack;
     CellBody* body;
     int32_t gw;
+    uint32_t cell_base;        // the keys count cells from this one on (a band of rows; 0: the whole grid)
     PSIM_HD void operator()(int64_t k) const
     {
         uint32_t p = cperm[k];
         PackedBody P = pack[p];
         CellBody b;
-        uint32_t c = ckey[k];
+        uint32_t c = ckey[k] + cell_base;
         b.x = P.x; b.y = P.y; b.r = P.r; b.idx = p; b.cell = c;
         b.cxy = (c % (uint32_t)gw) | ((c / (uint32_t)gw) << 16);
         body[k] = b;
+    }
+};
+
+// A band of whole cell rows [row_lo, row_hi) of the grid: which particles lie in it (flag,
+// scanned by the caller), then their cell ids relative to the band's first cell and their
+// indices, in ascending particle order (so that the stable sort by cell leaves each cell's
+// particles in ascending index, particle_system.py:759-763).
+struct BandFlag {
+    int64_t n;
+    const uint32_t* cell;      // global cell id per particle (DriftKeys)
+    int32_t gw, row_lo, row_hi;
+    uint32_t* flag;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        int32_t row = (int32_t)(cell[i] / (uint32_t)gw);
+        flag[i] = (row >= row_lo && row < row_hi) ? 1u : 0u;
+    }
+};
+struct BandCompact {
+    int64_t n;
+    const uint32_t* cell;
+    const uint32_t* flag;
+    const uint32_t* at;        // exclusive scan of flag
+    uint32_t cell_base;
+    uint32_t* key_out;
+    uint32_t* perm_out;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        if (!flag[i]) return;
+        uint32_t o = at[i];
+        key_out[o] = cell[i] - cell_base;
+        perm_out[o] = (uint32_t)i;
     }
 };
 
@@ -785,11 +818,25 @@ struct Kick {
 // (outer), p2 over the neighbour (inner), visited iff index(p1) < index(p2).
 // pair_key packs that order into one integer; a pair is always keyed from its
 // lower-index particle, whose cell is the home cell.
+// The grid may cover a band of whole cell rows only (one rank's slab of the domain plus its
+// halo rows, when the collision stage is split over several GPUs): cells keep their global
+// ids and rows, `offsets` is indexed by global cell id and holds the cells of rows
+// [row_lo, row_hi) only, slots are numbered from 0 inside the band.  The whole grid is the
+// band [0, gh).  [own_lo, own_hi) are the rows whose results this grid's owner keeps.
+struct CellOffsets {
+    const int32_t* p;          // [cells of the band + 1]
+    uint32_t base;             // global id of the band's first cell
+    PSIM_HD PSIM_FORCEINLINE int32_t operator[](int64_t cell) const { return p[cell - (int64_t)base]; }
+};
 struct GridView {
     const CellBody* body;      // slot -> {position, radius, particle index (grid_indices), cell}
-    const int32_t* offsets;    // cell -> first slot
+    CellOffsets offsets;       // cell -> first slot
     int32_t gw, gh;
     int32_t slot_bits;         // bits of the in-cell position fields of a pair key (>= bits of max occupancy)
+    int32_t row_lo, row_hi;    // rows the grid holds
+    int32_t own_lo, own_hi;    // rows owned
+    PSIM_HD PSIM_FORCEINLINE bool has_row(int ny) const { return ny >= row_lo && ny < row_hi; }
+    PSIM_HD PSIM_FORCEINLINE bool owns_row(int ny) const { return ny >= own_lo && ny < own_hi; }
 };
 
 // key = cell | phase:4 | a:slot_bits | b:slot_bits, packed tightly so that the
@@ -866,7 +913,7 @@ PSIM_HD PSIM_FORCEINLINE void for_each_neighbour_slot(const GridView& g, uint32_
         for (int dx = -1; dx <= 1; ++dx) {
             if (dx == 0 && dy == 0) continue;
             int nx = cx + dx, ny = cy + dy;
-            if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) continue;
+            if (nx < 0 || nx >= g.gw || !g.has_row(ny)) continue;
             uint32_t nc = (uint32_t)(ny * g.gw + nx);
             for (int32_t b = g.offsets[nc]; b < g.offsets[nc + 1]; ++b) f((uint32_t)b);
         }
@@ -888,7 +935,7 @@ PSIM_HD PSIM_FORCEINLINE void for_each_slot_in_cell(const GridView& g, uint32_t 
     uint32_t cxy = g.body[k].cxy;
     int cx = (int)(cxy & 0xffffu), cy = (int)(cxy >> 16);
     int nx = cx + (idx % 3 - 1), ny = cy + (idx / 3 - 1);
-    if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) return;
+    if (nx < 0 || nx >= g.gw || !g.has_row(ny)) return;
     uint32_t nc = (uint32_t)(ny * g.gw + nx);
     for (int32_t b = g.offsets[nc]; b < g.offsets[nc + 1]; ++b) f((uint32_t)b);
 }
@@ -903,7 +950,7 @@ PSIM_HD PSIM_FORCEINLINE bool cell_slot_range(const GridView& g, const CellBody&
         if (idx == 4) return false;
         int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
         int nx = cx + (idx % 3 - 1), ny = cy + (idx / 3 - 1);
-        if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) return false;
+        if (nx < 0 || nx >= g.gw || !g.has_row(ny)) return false;
         c = (uint32_t)(ny * g.gw + nx);
     }
     *lo = g.offsets[c];
@@ -971,7 +1018,7 @@ struct ContactDetect {
         const double px = me.x, py = me.y;
         const int32_t mr = me.r;
         const int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
-        const bool east = cx + 1 < g.gw, west = cx > 0, south = cy + 1 < g.gh;
+        const bool east = cx + 1 < g.gw, west = cx > 0, south = cy + 1 < g.row_hi;
         // Every position the grid puts into column cx + 1 or beyond has x >= (cx + 1) cell_size,
         // into row cy + 1 or beyond y >= (cy + 1) cell_size, into column cx - 1 or before
         // x < cx cell_size (particle_system.py:744-749; clipping only moves positions outwards).
@@ -1026,7 +1073,7 @@ struct ContactDetect {
         sweep(b_lo, b_hi);
         if (!WRITE) {
             counts[k] = found;
-            if (cand_counter) {
+            if (cand_counter && g.owns_row(cy)) {
                 // particle_system.py:156-197 visits every slot after k in its cell and every slot of the forward cells
                 int32_t nc = g.offsets[c + (east ? 2u : 1u)] - ((int32_t)k + 1);
                 if (south) {
@@ -1245,9 +1292,11 @@ struct ContactVelocity {
     const double* temp;
     const double* mass;
     double restitution;
+    const VelState* slot_state;   // optional: the slots' states before this sweep, in slot order (instead of vel / temp)
     PSIM_HD VelState fetch(uint32_t slot, int32_t pr) const
     {
         if (pr < 0) {
+            if (slot_state) return slot_state[slot];
             VelState s;
             uint32_t p = body[slot].idx;
             s.vel = vel[p];
@@ -1351,7 +1400,7 @@ PSIM_HD PSIM_FORCEINLINE bool cell_beyond_reach(const GridView& g, double cell_s
     int idx = which - 1;
     int cx = (int)(me.cxy & 0xffffu), cy = (int)(me.cxy >> 16);
     int nx = cx + (idx % 3 - 1), ny = cy + (idx / 3 - 1);
-    if (nx < 0 || nx >= g.gw || ny < 0 || ny >= g.gh) return true;       // no such cell
+    if (nx < 0 || nx >= g.gw || !g.has_row(ny)) return true;       // no such cell (in this grid)
     double gx = 0.0, gy = 0.0;
     if (nx > 0) { double lo = (double)nx * cell_size - me.x; if (lo > gx) gx = lo; }
     if (nx < g.gw - 1) { double hi = me.x - (double)(nx + 1) * cell_size; if (hi > gx) gx = hi; }
@@ -1787,7 +1836,7 @@ struct ContactFinalizePositions {
         cseg[x] = -1;
         body[x].x = s.x;
         body[x].y = s.y;
-        pos[body[x].idx] = s;
+        if (pos) pos[body[x].idx] = s;      // (null: the caller exports the touched slots' states instead)
     }
 };
 
@@ -1800,6 +1849,7 @@ struct ContactFinalizeVelocities {
     const CellBody* body;
     vec2* vel;
     double* temp;
+    VelState* slot_out;       // optional: written (by slot) instead of vel / temp
     PSIM_HD void operator()(int64_t e) const
     {
         uint32_t x = (uint32_t)(adj[e] >> 32);
@@ -1808,6 +1858,7 @@ struct ContactFinalizeVelocities {
         uint32_t h = (uint32_t)adj[e];
         int side = (hsi[h] == x) ? 0 : 1;
         VelState s = out[2 * h + side];
+        if (slot_out) { slot_out[x] = s; return; }
         uint32_t p = body[x].idx;
         vel[p] = s.vel;
         temp[p] = s.temp;
@@ -1828,13 +1879,28 @@ struct ContactLog {
     double* sum_pe;
     double* sum_ke;
     double* sum_heat;
+    // a grid that is one rank's band of rows: only the contacts whose home cell (the cell of
+    // the lower-index particle, slot hsi) lies in the owned rows are counted and logged;
+    // the others are counted by the neighbouring rank
+    int32_t own_lo, own_hi;
+    uint32_t* owned_count;    // optional
     PSIM_HD void operator()(int64_t h) const
     {
         double pe = vals[3 * h], ke = vals[3 * h + 1], heat = vals[3 * h + 2];
-        sum_pe[h] = pe;
-        sum_ke[h] = ke;
-        sum_heat[h] = heat > 0 ? heat : 0.0;
+        int32_t row = (int32_t)(body[hsi[h]].cxy >> 16);
+        bool own = row >= own_lo && row < own_hi;
+        sum_pe[h] = own ? pe : 0.0;
+        sum_ke[h] = own ? ke : 0.0;
+        sum_heat[h] = (own && heat > 0) ? heat : 0.0;
         int64_t at = log_base + h;
+        if (!own) {
+            if (log_ij && at < log_cap) {
+                log_ij[2 * at] = -1; log_ij[2 * at + 1] = -1;
+                log_vals[3 * at] = 0.0; log_vals[3 * at + 1] = 0.0; log_vals[3 * at + 2] = 0.0;
+            }
+            return;
+        }
+        if (owned_count) aggregated_inc(owned_count);
         if (log_ij && at < log_cap) {
             log_ij[2 * at] = (int32_t)body[hsi[h]].idx;
             log_ij[2 * at + 1] = (int32_t)body[hsj[h]].idx;
@@ -1864,13 +1930,11 @@ struct Conduction {
     double heat_coeff;
     double cool_factor;       // 1 - damping
     int32_t do_conduct, do_cool;
-    double* temp;             // index space, written (when temp_slots is null)
-    double* temp_slots;       // slot space, written instead (sharded sweep)
+    double* temp;             // index space, written
     double* delta_out;        // optional debug, index space
-    int64_t k0;               // first slot of this launch
     PSIM_HD void operator()(int64_t kk) const
     {
-        uint32_t k = (uint32_t)(k0 + kk);
+        uint32_t k = (uint32_t)kk;
         const CellBody me = g.body[k];
         uint32_t p = me.idx;
         double T = ctemp[k];
@@ -1896,7 +1960,7 @@ struct Conduction {
         }
         double T1 = T + delta;
         if (do_cool) T1 = T1 * cool_factor;
-        if (temp_slots) temp_slots[k] = T1; else temp[p] = T1;
+        temp[p] = T1;
         if (delta_out) delta_out[p] = delta;
     }
 };
@@ -1918,13 +1982,6 @@ struct ScatterSorted {
     const vec2* in_sorted;
     vec2* out;
     PSIM_HD void operator()(int64_t k) const { out[perm[order ? order[k] : (uint32_t)k]] = in_sorted[k]; }
-};
-struct ScatterSlots {
-    int64_t n;
-    const CellBody* body;
-    const double* in_slots;
-    double* out;
-    PSIM_HD void operator()(int64_t k) const { out[body[k].idx] = in_slots[k]; }
 };
 
 // ---- conduction without a second full sweep.  After the collision stage a pair of
@@ -1996,15 +2053,26 @@ struct ConductionApply {
     const double* mass;
     double heat_coeff;
     double* delta;             // index space, zero elsewhere
+    // When the collision stage left its results in slot order (slot_state, valid where
+    // moved[slot]) instead of writing them to temp[]: read them there, and file the sum under
+    // the target's first entry (slot_delta[e]) for the caller to export.
+    const VelState* slot_state;
+    const uint8_t* moved;
+    double* slot_delta;
+    PSIM_HD PSIM_FORCEINLINE double temp_of(uint32_t slot, uint32_t p) const
+    {
+        return (slot_state && moved[slot]) ? slot_state[slot].temp : temp[p];
+    }
     PSIM_HD void operator()(int64_t e) const
     {
         uint32_t t = (uint32_t)(entries[e] >> 32);
         if (e > 0 && (uint32_t)(entries[e - 1] >> 32) == t) return;
         uint32_t pt = body[t].idx;
-        double Tt = temp[pt], m = mass[pt], d = 0.0;
+        double Tt = temp_of(t, pt), m = mass[pt], d = 0.0;
         for (int64_t k = e; k < n_entries && (uint32_t)(entries[k] >> 32) == t; ++k) {
-            uint32_t ps = body[(uint32_t)entries[k]].idx;
-            double Ts = temp[ps];
+            uint32_t ys = (uint32_t)entries[k];
+            uint32_t ps = body[ys].idx;
+            double Ts = temp_of(ys, ps);
             if (pt < ps) {
                 double diff = Tt - Ts;
                 if (diff != 0) d -= (heat_coeff * diff) / m;
@@ -2013,7 +2081,215 @@ struct ConductionApply {
                 if (diff != 0) d += (heat_coeff * diff) / m;
             }
         }
-        delta[pt] = d;
+        if (slot_delta) slot_delta[e] = d; else delta[pt] = d;
+    }
+};
+
+// ---- The collision stage split over several GPUs by bands of grid rows.  A rank solves the
+// band it owns plus halo rows on a grid of that band only, leaves the state arrays alone and
+// exports, as 64-bit words, (a) the state of every touched slot of its OWN rows, (b) the
+// conduction sum of every target in its own rows, (c) for each of its two seams, a record of
+// every contact that involves a slot of the two rows along the seam.  The ranks exchange the
+// blocks; the results are applied only when both ranks along every seam hold identical seam
+// records (then every rank's view of its neighbours' rows was the true one, and the union of
+// the owned results is the sequential sweep's result).
+constexpr int kExportHeaderWords = 32;
+constexpr int kExportStateWords = 6;      // particle index, x, y, vx, vy, T
+constexpr int kExportDeltaWords = 2;      // particle index, sum of conduction terms
+constexpr int kExportSeamWords = 11;      // index i << 32 | index j, positions after (i, j), velocity + temperature after (i, j)
+
+PSIM_HD PSIM_FORCEINLINE uint64_t f64_bits(double v) { uint64_t b; __builtin_memcpy(&b, &v, 8); return b; }
+PSIM_HD PSIM_FORCEINLINE double bits_f64(uint64_t b) { double v; __builtin_memcpy(&v, &b, 8); return v; }
+
+struct ExportStateFlag {
+    int64_t n_moved;
+    const uint32_t* list;      // touched slots
+    const CellBody* body;
+    int32_t own_lo, own_hi;
+    uint32_t* flag;
+    PSIM_HD void operator()(int64_t m) const
+    {
+        int32_t row = (int32_t)(body[list[m]].cxy >> 16);
+        flag[m] = (row >= own_lo && row < own_hi) ? 1u : 0u;
+    }
+};
+struct ExportStateWrite {
+    int64_t n_moved;
+    const uint32_t* list;
+    const uint32_t* flag;
+    const uint32_t* at;
+    const CellBody* body;
+    const VelState* slot_state;
+    uint64_t* out;
+    PSIM_HD void operator()(int64_t m) const
+    {
+        if (!flag[m]) return;
+        uint32_t x = list[m];
+        const CellBody b = body[x];
+        const VelState v = slot_state[x];
+        uint64_t* o = out + (size_t)kExportStateWords * at[m];
+        o[0] = (uint64_t)b.idx; o[1] = f64_bits(b.x); o[2] = f64_bits(b.y);
+        o[3] = f64_bits(v.vel.x); o[4] = f64_bits(v.vel.y); o[5] = f64_bits(v.temp);
+    }
+};
+struct ExportDeltaFlag {
+    int64_t n_entries;
+    const uint64_t* entries;   // sorted by target slot
+    const CellBody* body;
+    int32_t own_lo, own_hi;
+    uint32_t* flag;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        uint32_t t = (uint32_t)(entries[e] >> 32);
+        bool first = e == 0 || (uint32_t)(entries[e - 1] >> 32) != t;
+        int32_t row = (int32_t)(body[t].cxy >> 16);
+        flag[e] = (first && row >= own_lo && row < own_hi) ? 1u : 0u;
+    }
+};
+struct ExportDeltaWrite {
+    int64_t n_entries;
+    const uint64_t* entries;
+    const uint32_t* flag;
+    const uint32_t* at;
+    const CellBody* body;
+    const double* slot_delta;  // [entry]
+    uint64_t* out;
+    PSIM_HD void operator()(int64_t e) const
+    {
+        if (!flag[e]) return;
+        uint64_t* o = out + (size_t)kExportDeltaWords * at[e];
+        o[0] = (uint64_t)body[(uint32_t)(entries[e] >> 32)].idx;
+        o[1] = f64_bits(slot_delta[e]);
+    }
+};
+// contacts of the settled list that involve a slot of row seam - 1 or row seam
+struct SeamFlag {
+    int64_t n;
+    const uint32_t* hsi;
+    const uint32_t* hsj;
+    const CellBody* body;
+    int32_t seam;
+    uint32_t* flag;
+    PSIM_HD void operator()(int64_t h) const
+    {
+        int32_t ri = (int32_t)(body[hsi[h]].cxy >> 16), rj = (int32_t)(body[hsj[h]].cxy >> 16);
+        flag[h] = (ri == seam || ri == seam - 1 || rj == seam || rj == seam - 1) ? 1u : 0u;
+    }
+};
+struct SeamWrite {
+    int64_t n;
+    const uint32_t* hsi;
+    const uint32_t* hsj;
+    const uint32_t* flag;
+    const uint32_t* at;
+    const CellBody* body;
+    const vec2* outp;
+    const VelState* outv;
+    uint64_t* out;             // already offset to the first free record
+    PSIM_HD void operator()(int64_t h) const
+    {
+        if (!flag[h]) return;
+        uint64_t* o = out + (size_t)kExportSeamWords * at[h];
+        const vec2 a = outp[2 * h], b = outp[2 * h + 1];
+        const VelState va = outv[2 * h], vb = outv[2 * h + 1];
+        o[0] = ((uint64_t)body[hsi[h]].idx << 32) | (uint64_t)body[hsj[h]].idx;
+        o[1] = f64_bits(a.x); o[2] = f64_bits(a.y); o[3] = f64_bits(b.x); o[4] = f64_bits(b.y);
+        o[5] = f64_bits(va.vel.x); o[6] = f64_bits(va.vel.y); o[7] = f64_bits(va.temp);
+        o[8] = f64_bits(vb.vel.x); o[9] = f64_bits(vb.vel.y); o[10] = f64_bits(vb.temp);
+    }
+};
+struct ExportHeader {
+    uint64_t words[kExportHeaderWords];
+    uint64_t* out;
+    PSIM_HD void operator()(int64_t i) const { out[i] = words[i]; }       // launched over kExportHeaderWords
+};
+// the blocks' headers side by side (one copy to the host instead of one per block)
+struct GatherHeaders {
+    int64_t world;
+    int64_t block_words;
+    const uint64_t* blocks;
+    uint64_t* out;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        int64_t r = i / kExportHeaderWords, w = i - r * kExportHeaderWords;
+        out[i] = blocks[r * block_words + w];
+    }
+};
+struct ApplyState {
+    int64_t n_rec;
+    const uint64_t* rec;
+    vec2* pos;
+    vec2* vel;
+    double* temp;
+    PSIM_HD void operator()(int64_t k) const
+    {
+        const uint64_t* o = rec + (size_t)kExportStateWords * k;
+        uint32_t p = (uint32_t)o[0];
+        vec2 x, v;
+        x.x = bits_f64(o[1]); x.y = bits_f64(o[2]); v.x = bits_f64(o[3]); v.y = bits_f64(o[4]);
+        pos[p] = x;
+        vel[p] = v;
+        temp[p] = bits_f64(o[5]);
+    }
+};
+struct ApplyDelta {
+    int64_t n_rec;
+    const uint64_t* rec;
+    double* delta;
+    PSIM_HD void operator()(int64_t k) const
+    {
+        const uint64_t* o = rec + (size_t)kExportDeltaWords * k;
+        delta[(uint32_t)o[0]] = bits_f64(o[1]);
+    }
+};
+// number of slots in the cells [cell_lo, cell_hi) (relative to the first cell the offsets hold)
+struct OwnedSlots {
+    const int32_t* offsets;
+    int64_t cell_lo, cell_hi;
+    uint32_t* out;
+    PSIM_HD void operator()(int64_t) const { *out = (uint32_t)(offsets[cell_hi] - offsets[cell_lo]); }
+};
+// slot records were made from the drifted positions; bring them up to the current ones
+struct RefreshBodyPositions {
+    int64_t n;
+    CellBody* body;
+    const vec2* pos;
+    PSIM_HD void operator()(int64_t k) const
+    {
+        vec2 p = pos[body[k].idx];
+        body[k].x = p.x;
+        body[k].y = p.y;
+    }
+};
+// the grid cell ids of DriftKeys again, from the records it wrote (the cell sort works in place)
+struct CellKeysFromPack {
+    int64_t n;
+    const PackedBody* pack;
+    double cell_size;
+    int32_t gw, gh;
+    uint32_t* ckey;
+    uint32_t* cperm;
+    PSIM_HD void operator()(int64_t i) const
+    {
+        int32_t cx = cell_coord(pack[i].x, cell_size, gw);
+        int32_t cy = cell_coord(pack[i].y, cell_size, gh);
+        ckey[i] = (uint32_t)(cy * gw + cx);
+        cperm[i] = (uint32_t)i;
+    }
+};
+// slot -> velocity and temperature of its particle (the velocity half's initial states in slot order)
+struct GatherSlotState {
+    int64_t n;
+    const CellBody* body;
+    const vec2* vel;
+    const double* temp;
+    VelState* out;
+    PSIM_HD void operator()(int64_t k) const
+    {
+        uint32_t p = body[k].idx;
+        VelState s;
+        s.vel = vel[p]; s.temp = temp[p]; s.unused = 0.0;
+        out[k] = s;
     }
 };
 
@@ -2116,7 +2392,7 @@ struct ExplosionGather {
         double total = 0.0;
         uint32_t cnt = 0;
         int64_t x = cx + dx, y = cy + dy;
-        if (!(x < 0 || x >= g.gw || y < 0 || y >= g.gh)) {
+        if (!(x < 0 || x >= g.gw || y < g.row_lo || y >= g.row_hi)) {
             uint32_t at = write_pass ? offsets[r] + cell_at[i] : 0u;
             int64_t c = y * g.gw + x;
             for (int32_t k = g.offsets[c]; k < g.offsets[c + 1]; ++k) {

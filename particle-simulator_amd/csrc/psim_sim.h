@@ -132,6 +132,25 @@ public:
     DevBuf<uint32_t> ckey[2], cperm[2];
     DevBuf<int32_t> offsets;
     DevBuf<CellBody> cbody;
+    // The grid of the step: the whole domain (one GPU), or a band of whole cell rows -- the rows
+    // a rank owns plus halo rows -- when the collision stage is split over several GPUs.
+    // ns = slots (particles) in it.  With `deferred` the collision stage leaves the state arrays
+    // alone: results stay in slot order (cbody, slot_state, slot_delta) and are exported.
+    struct Band { int32_t row_lo, row_hi, own_lo, own_hi; };
+    Band band{0, 0, 0, 0};
+    bool band_partial = false;
+    int64_t ns = 0;
+    bool full_grid_valid = false;      // cbody / offsets hold the whole grid of this step's drifted positions
+    bool deferred = false;
+    bool slot_state_full = false;      // slot_state holds every slot's state (sweeps after the first read it)
+    DevBuf<uint32_t> bflag, bat, rkey[2], rperm[2];
+    DevBuf<VelState> slot_state;
+    DevBuf<double> slot_delta;
+    DevBuf<uint64_t> seam_rec[2];      // records of the contacts along the band's lower / upper seam
+    int64_t seam_n[2] = {0, 0};
+    DevBuf<uint64_t> hdr_dev;
+    int64_t own_slots = 0;
+    int64_t slab_fallbacks = 0;        // steps whose seam records disagreed (solved again on the whole grid)
     DevBuf<double> ctemp;
     DevBuf<int32_t> cseg;
     bool cseg_ready = false;
@@ -423,11 +442,20 @@ public:
     {
         GridView g;
         g.body = cbody.p;
-        g.offsets = offsets.p;
+        g.offsets.p = offsets.p;
+        g.offsets.base = band_partial ? (uint32_t)band.row_lo * (uint32_t)cfg.grid_w : 0u;
         g.gw = cfg.grid_w;
         g.gh = cfg.grid_h;
         g.slot_bits = slot_bits;
+        g.row_lo = band_partial ? band.row_lo : 0;
+        g.row_hi = band_partial ? band.row_hi : cfg.grid_h;
+        g.own_lo = deferred ? band.own_lo : 0;
+        g.own_hi = deferred ? band.own_hi : cfg.grid_h;
         return g;
+    }
+    int64_t band_cells() const
+    {
+        return band_partial ? (int64_t)(band.row_hi - band.row_lo) * cfg.grid_w : (int64_t)cfg.grid_w * cfg.grid_h;
     }
 
     // -------------------------------------------------------------- stages
@@ -444,15 +472,21 @@ public:
         pack.ensure(c);
         k.mass = mass.p; k.radii = radii.p; k.pack = pack.p;
         be::launch(st, n, k);
+        cell_keys_sorted = false;
+        full_grid_valid = false;
     }
 
     // particle_system.py:732-763
     void build_grid() { build_grid(st, sort_tmp); }
+    bool cell_keys_sorted = false;     // ckey[0] / cperm[0] no longer hold what DriftKeys wrote
     void build_grid(be::Stream s, DevBuf<uint32_t>& tmp)
     {
         size_t c = (size_t)n;
         uint64_t cells = (uint64_t)cfg.grid_w * (uint64_t)cfg.grid_h;
         tmp.ensure(be::sort_temp_words(c));
+        if (cell_keys_sorted && n > 0)
+            be::launch(s, n, CellKeysFromPack{n, pack.p, (double)cfg.cell_size, cfg.grid_w, cfg.grid_h, ckey[0].p, cperm[0].p});
+        cell_keys_sorted = true;
         uint32_t* k[2] = {ckey[0].p, ckey[1].p};
         uint32_t* v[2] = {cperm[0].p, cperm[1].p};
         int bits = ceil_log2_u64(cells);
@@ -466,8 +500,71 @@ public:
             be::dev_memset(s, offsets.p, 0, (cells + 1) * sizeof(int32_t));
         }
         cbody.ensure(c);
-        be::launch(s, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pack.p, cbody.p, cfg.grid_w});
+        be::launch(s, n, GatherCell{n, cperm[sorted_ckey].p, ckey[sorted_ckey].p, pack.p, cbody.p, cfg.grid_w, 0u});
         tree_n = n;
+        ns = n;
+        band = Band{0, cfg.grid_h, 0, cfg.grid_h};
+        band_partial = false;
+        full_grid_valid = true;
+    }
+    // The whole grid, built late in a step that worked on a band of rows (explosions and the
+    // full conduction sweep want every cell); the cell ids DriftKeys wrote are still in place.
+    void ensure_full_grid()
+    {
+        if (full_grid_valid) return;
+        build_grid(st, sort_tmp);
+        // (the slot records are made from the drifted positions; the collision stage may have moved particles since)
+        if (n > 0) be::launch(st, n, RefreshBodyPositions{n, cbody.p, pos.p});
+    }
+
+    // The grid of the rows [b.row_lo, b.row_hi) only: the particles of those rows compacted in
+    // ascending index, sorted by cell (relative to the band's first cell), CSR over the
+    // band's cells, slot records.  One small readback (the band's population sizes the sort).
+    void build_grid_band(const Lane& ln, const Band& b)
+    {
+        if (b.row_lo < 0 || b.row_hi > cfg.grid_h || b.row_lo >= b.row_hi || b.own_lo < b.row_lo || b.own_hi > b.row_hi ||
+            b.own_lo > b.own_hi)
+            throw std::invalid_argument("psim: bad band of grid rows");
+        if (b.row_lo == 0 && b.row_hi == cfg.grid_h) {
+            build_grid(ln.s, *ln.sort_tmp);
+            band = b;
+            return;
+        }
+        if (cell_keys_sorted)
+            be::launch(ln.s, n, CellKeysFromPack{n, pack.p, (double)cfg.cell_size, cfg.grid_w, cfg.grid_h, ckey[0].p, cperm[0].p});
+        cell_keys_sorted = false;
+        const size_t c = (size_t)n;
+        const int64_t bcells = (int64_t)(b.row_hi - b.row_lo) * cfg.grid_w;
+        const uint32_t cell_base = (uint32_t)b.row_lo * (uint32_t)cfg.grid_w;
+        band = b;
+        band_partial = true;
+        full_grid_valid = false;
+        offsets.ensure((size_t)cfg.grid_w * (size_t)cfg.grid_h + 1);
+        ns = 0;
+        if (n > 0) {
+            bflag.ensure(c); bat.ensure(c);
+            ln.scan_tmp->ensure_zero(ln.s, be::scan_temp_words(c));
+            be::launch(ln.s, n, BandFlag{n, ckey[0].p, cfg.grid_w, b.row_lo, b.row_hi, bflag.p});
+            be::exclusive_scan_u32(ln.s, bflag.p, bat.p, (uint64_t)n, ln.scan_tmp->p, ln.ctr + 12, small_groups_now(ln.small_groups));
+            ns = read_u32(ln, ln.ctr + 12);
+        }
+        if (ns == 0) {
+            be::dev_memset(ln.s, offsets.p, 0, ((size_t)bcells + 1) * sizeof(int32_t));
+            return;
+        }
+        const size_t cs = (size_t)ns;
+        rkey[0].ensure(cs); rkey[1].ensure(cs); rperm[0].ensure(cs); rperm[1].ensure(cs);
+        be::launch(ln.s, n, BandCompact{n, ckey[0].p, bflag.p, bat.p, cell_base, rkey[0].p, rperm[0].p});
+        ln.sort_tmp->ensure(be::sort_temp_words(cs));
+        uint32_t* k[2] = {rkey[0].p, rkey[1].p};
+        uint32_t* v[2] = {rperm[0].p, rperm[1].p};
+        int bits = ceil_log2_u64((uint64_t)bcells);
+        if (bits < 1) bits = 1;
+        const int sorted = be::radix_sort_pairs<uint32_t>(ln.s, k, v, (uint64_t)ns, 0, bits, ln.sort_tmp->p);
+        be::launch(ln.s, ns, SegmentOffsets{ns, rkey[sorted].p, offsets.p, (uint32_t)bcells});
+        be::launch(ln.s, bcells + 1, SegmentOffsetsTail{ns, rkey[sorted].p, offsets.p, (uint32_t)bcells});
+        cbody.ensure(c);
+        be::launch(ln.s, ns, GatherCell{ns, rperm[sorted].p, rkey[sorted].p, pack.p, cbody.p, cfg.grid_w, cell_base});
     }
 
     // count pass of the first collision sweep (positions do not change between the drift and
@@ -478,9 +575,9 @@ public:
     void detect_count(be::Stream s, DevBuf<uint32_t>& scan_scratch, uint32_t* ctr, bool small_groups, int64_t k_lo = 0,
                       int64_t k_hi = -1)
     {
-        size_t c = (size_t)n;
-        if (k_hi < 0) k_hi = n;
-        const int64_t cells = (int64_t)cfg.grid_w * cfg.grid_h;
+        size_t c = (size_t)ns;
+        if (k_hi < 0) k_hi = ns;
+        const int64_t cells = band_cells();
         GridView g = grid_view();
         pcount.ensure(c); poffs.ensure(c); first_key.ensure((size_t)kDetectKept * c / 2 + 1); scan_scratch.ensure_zero(s, be::scan_temp_words(c));
         be::dev_memset(s, ctr, 0, 64);
@@ -757,7 +854,9 @@ public:
         settled_contacts = 0; settled_rounds = 0; settled_adj = nullptr;
         cond_pairs_ready = false;
         positions_settled = true;
-        if (n == 0 || cfg.solver_iterations <= 0) return;
+        seam_n[0] = seam_n[1] = 0;
+        slot_state_full = false;
+        if (n == 0 || ns == 0 || cfg.solver_iterations <= 0) return;
         if (!cseg_ready || cseg.cap < (size_t)n) {
             cseg.ensure((size_t)n);
             be::launch(ln.s, (int64_t)cseg.cap, FillI32{(int64_t)cseg.cap, cseg.p, -1});
@@ -767,7 +866,7 @@ public:
         ln.sort_tmp->ensure(be::sort_temp_words(2 * ccap));
         moved.ensure((size_t)n);
         moved_list.ensure((size_t)n);
-        be::dev_memset(ln.s, moved.p, 0, (size_t)n);
+        be::dev_memset(ln.s, moved.p, 0, (size_t)ns);
         sweep_positions(ln, 0);
         if (cfg.solver_iterations == 1) {
             moved_valid = true;
@@ -777,8 +876,15 @@ public:
 
     void collisions_velocities()
     {
-        if (n == 0 || cfg.solver_iterations <= 0) { moved_valid = cfg.solver_iterations > 0; return; }
+        if (n == 0 || ns == 0 || cfg.solver_iterations <= 0) { moved_valid = cfg.solver_iterations > 0; return; }
         Lane ln = main_lane();
+        if (deferred && cfg.solver_iterations > 1) {
+            // sweeps after the first start from the states the sweep before left, which in this
+            // mode are not in vel[] / temp[]: keep every slot's state in slot order
+            slot_state.ensure((size_t)n);
+            be::launch(st, ns, GatherSlotState{ns, cbody.p, vel.p, temp.p, slot_state.p});
+            slot_state_full = true;
+        }
         sweep_velocities(0);
         for (int it = 1; it < cfg.solver_iterations; ++it) {
             sweep_positions(ln, it);
@@ -807,11 +913,6 @@ public:
         if (bits > 64) throw std::runtime_error("psim: grid cell population too large for the pair-key layout");
         return bits;
     }
-    // contact keys of sweep 0 handed in by the caller (stage_detect on every rank + gather)
-    const uint64_t* ext_keys = nullptr;
-    bool ext_given = false;
-    int64_t ext_n0 = 0, ext_candidates = 0, ext_coincident = 0;
-
     // ContactDetect may skip forward cells by distance to the shared border only while the
     // slot records hold the positions the grid was built from (the step's first sweep)
     bool detect_prune = true;
@@ -820,27 +921,14 @@ public:
     {
         if (sweep > 0) detect_prune = false;
         GridView g = grid_view();
-        const int slot_field_bits = ceil_log2_u64((uint64_t)n + 1);
+        const int slot_field_bits = ceil_log2_u64((uint64_t)ns + 1);
         uint32_t* const ctr = ln.ctr;
         DevBuf<uint32_t>& scan_scratch = *ln.scan_tmp;
         settled_contacts = 0; settled_rounds = 0; settled_adj = nullptr;
         // ---- sweep against the initial positions (count, scan, write)
         uint32_t n0 = 0, cand = 0;
         int key_bits = 64;
-        if (sweep == 0 && ext_given) {
-            // the initial sweep's contact keys were detected elsewhere (slabs of slots on several
-            // ranks, gathered by the caller): take them as they are
-            n0 = (uint32_t)ext_n0; cand = (uint32_t)ext_candidates;
-            n_coincident = (uint32_t)ext_coincident;
-            g.slot_bits = slot_bits;
-            key_bits = pair_key_bits();
-            if (n0 > 0) {
-                ensure_contact_capacity(ln, n0);
-                be::launch(ln.s, n0, CopyWords{(int64_t)n0, ext_keys, h0[0].p});
-            }
-            ext_given = false;
-            predetected = false;
-        } else {
+        {
             const uint32_t* dctr = ctr;
             if (sweep == 0 && predetected) {
                 dctr = counters2.p;         // already computed on the side stream (this lane, or joined by the caller)
@@ -850,7 +938,7 @@ public:
             }
             ContactDetect d;
             d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
-            d.n = n; d.k0 = 0; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = reinterpret_cast<uint32_t*>(first_key.p);
+            d.n = ns; d.k0 = 0; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = reinterpret_cast<uint32_t*>(first_key.p);
             d.coincident_counter = nullptr;
             uint32_t three[4];
             readback_on(ln, three, dctr, 16);
@@ -863,7 +951,7 @@ public:
                 ensure_contact_capacity(ln, n0);
                 d.g = g;
                 d.out_keys = h0[0].p; d.write_pass = 1; d.cand_counter = nullptr;
-                be::launch(ln.s, n, d);
+                be::launch(ln.s, ns, d);
             }
         }
         n_candidates += cand;
@@ -1055,7 +1143,7 @@ public:
         pcount.ensure(2 * (size_t)nH); poffs.ensure(2 * (size_t)nH);
         ContactFinalizePositions f;
         f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outp.p; f.body = cbody.p;
-        f.pos = pos.p; f.moved = moved.p; f.newly = pcount.p;
+        f.pos = deferred ? nullptr : pos.p; f.moved = moved.p; f.newly = pcount.p;
         be::launch(ln.s, 2ll * nH, f);
         be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, 2ull * nH, scan_scratch.p, ctr + 5, small_groups_now(ln.small_groups));
         be::launch(ln.s, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
@@ -1082,6 +1170,7 @@ public:
             v.n = nH; v.hsi = hsi.p; v.hsj = hsj.p; v.prev = prevl.p; v.done = done.p; v.round = r; v.out = outv.p;
             v.geo = cgeo.p; v.vals = cvals.p; v.body = cbody.p; v.vel = vel.p; v.temp = temp.p; v.mass = mass.p;
             v.restitution = cfg.restitution;
+            v.slot_state = slot_state_full ? slot_state.p : nullptr;
 #if defined(PSIM_HOSTLOOP)
             be::launch(st, nH, v);
 #else
@@ -1092,7 +1181,7 @@ public:
         size_t log_cap = 0;
         if (cfg.debug) {
             log_cap = (size_t)log_n + nH;
-            if (log_ij.cap < 2 * log_cap) {
+            if (log_ij.cap < 2 * log_cap || log_vals.cap < 3 * log_cap) {
                 DevBuf<int32_t> nij; DevBuf<double> nv;
                 nij.ensure(2 * log_cap); nv.ensure(3 * log_cap);
                 if (log_n) {
@@ -1108,6 +1197,9 @@ public:
         cl.log_ij = cfg.debug ? log_ij.p : nullptr; cl.log_vals = cfg.debug ? log_vals.p : nullptr;
         cl.log_base = log_n; cl.log_cap = (int64_t)log_cap;
         cl.sum_pe = sum_pe.p; cl.sum_ke = sum_ke.p; cl.sum_heat = sum_heat.p;
+        cl.own_lo = deferred ? band.own_lo : 0; cl.own_hi = deferred ? band.own_hi : cfg.grid_h;
+        cl.owned_count = deferred ? step_words.p + 8 : nullptr;
+        if (deferred) be::dev_memset(st, step_words.p + 8, 0, 16);
         be::launch(st, nH, cl);
         const bool last_sweep = sweep + 1 >= cfg.solver_iterations;
         double* totals_dev = last_sweep ? reinterpret_cast<double*>(step_words.p) : red_out.p;
@@ -1115,44 +1207,76 @@ public:
         ContactFinalizeVelocities f;
         f.n_adj = 2ll * nH; f.adj = settled_adj; f.hsi = hsi.p; f.out = outv.p; f.body = cbody.p; f.vel = vel.p;
         f.temp = temp.p;
+        f.slot_out = nullptr;
+        if (deferred) { slot_state.ensure((size_t)n); f.slot_out = slot_state.p; }
         be::launch(st, 2ll * nH, f);
+        if (deferred) {
+            // the contacts along the band's two seams, for the neighbours to compare with theirs
+            // (appended sweep by sweep), and the number of contacts of the owned rows
+            const int32_t seams[2] = {band.own_lo, band.own_hi};
+            bool any = false;
+            pcount.ensure(2 * (size_t)nH); poffs.ensure(2 * (size_t)nH);
+            scan_tmp.ensure_zero(st, be::scan_temp_words(nH));
+            for (int k = 0; k < 2; ++k) {
+                if (seams[k] <= 0 || seams[k] >= cfg.grid_h) continue;       // the domain's edge: no neighbour
+                any = true;
+                be::launch(st, nH, SeamFlag{(int64_t)nH, hsi.p, hsj.p, cbody.p, seams[k], pcount.p + (size_t)k * nH});
+                be::exclusive_scan_u32(st, pcount.p + (size_t)k * nH, poffs.p + (size_t)k * nH, nH, scan_tmp.p, step_words.p + 9 + k);
+            }
+            uint32_t w[3];
+            readback(w, step_words.p + 8, 12);
+            n_contacts += w[0];
+            for (int k = 0; k < 2 && any; ++k) {
+                if (seams[k] <= 0 || seams[k] >= cfg.grid_h || w[1 + k] == 0) continue;
+                const size_t have = (size_t)seam_n[k], add = w[1 + k];
+                if (seam_rec[k].cap < (have + add) * kExportSeamWords) {
+                    DevBuf<uint64_t> grown;
+                    grown.ensure((have + add) * kExportSeamWords * 2);
+                    if (have) be::copy_d2d(st, grown.p, seam_rec[k].p, have * kExportSeamWords * 8);
+                    be::sync(st);
+                    seam_rec[k].swap(grown);
+                }
+                be::launch(st, nH, SeamWrite{(int64_t)nH, hsi.p, hsj.p, pcount.p + (size_t)k * nH, poffs.p + (size_t)k * nH, cbody.p,
+                                             outp.p, outv.p, seam_rec[k].p + have * kExportSeamWords});
+                seam_n[k] += add;
+            }
+        } else {
+            n_contacts += nH;
+        }
         if (last_sweep) {
-            totals_pending = true;       // fetched with the explosion count (walls_and_flags)
+            totals_pending = true;       // fetched with the explosion count (walls_and_flags) or by the export
         } else {
             double t[3];
             readback(t, red_out.p, 24);
             coll_totals[0] += t[0]; coll_totals[1] += t[1]; coll_totals[2] += t[2];
         }
-        n_contacts += nH;
         if (cfg.debug) log_n += nH;
         settled_contacts = 0;
     }
 
-    // particle_system.py:476-498 + :555-557.  Slots [lo, hi) only; with temp_slots the
-    // new temperatures are written in slot order (sharded sweep) instead of to temp[].
-    void conduction_and_cooling(int64_t lo, int64_t hi, double* temp_slots)
+    // particle_system.py:476-498 + :555-557 as a sweep over every slot of the (whole) grid
+    void conduction_and_cooling()
     {
         bool cond = (cfg.stage_mask & kStageConduction) != 0;
         bool cool = (cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0;
         if (n == 0 || (!cond && !cool)) return;
         double factor = 1.0 - cfg.damping;
         if (!cond) {
-            if (!temp_slots) be::launch(st, n, Cooling{n, temp.p, factor});
+            be::launch(st, n, Cooling{n, temp.p, factor});
             return;
         }
+        if (band_partial || ns != n) throw std::runtime_error("psim: internal: full conduction sweep on a partial grid");
         size_t c = (size_t)n;
         ctemp.ensure(c);
         GridView g = grid_view();
         be::launch(st, n, GatherThermal{n, cbody.p, temp.p, ctemp.p});
         if (cfg.debug) delta_dbg.ensure(c);
-        if (hi <= lo) return;
         Conduction k;
-        k.n = hi - lo; k.g = g; k.ctemp = ctemp.p; k.mass = mass.p;
+        k.n = n; k.g = g; k.ctemp = ctemp.p; k.mass = mass.p;
         k.heat_coeff = cfg.heat_coeff; k.cool_factor = factor; k.do_conduct = 1; k.do_cool = cool ? 1 : 0;
-        k.temp = temp.p; k.temp_slots = temp_slots; k.delta_out = cfg.debug ? delta_dbg.p : nullptr; k.k0 = lo;
-        be::launch(st, hi - lo, k);
+        k.temp = temp.p; k.delta_out = cfg.debug ? delta_dbg.p : nullptr;
+        be::launch(st, n, k);
     }
-    void conduction_and_cooling() { conduction_and_cooling(0, n, nullptr); }
 
     // The touching pairs all involve a slot the collision stage touched (see
     // ConductionPairs): possible when that stage ran this step and met no pair at
@@ -1192,7 +1316,7 @@ public:
         k.entries = cond_entries[0].p; k.write_pass = 1;
         be::launch(ln.s, nt, k);
         uint64_t* ke[2] = {cond_entries[0].p, cond_entries[1].p};
-        int bits = 32 + ceil_log2_u64((uint64_t)n + 1);
+        int bits = 32 + ceil_log2_u64((uint64_t)ns + 1);
         // targets in ascending slot order; a stable sort on the target field alone keeps the
         // sources of one target in the (fixed) order the pairs were written
         cond_sorted = be::radix_sort_pairs<uint64_t>(ln.s, ke, nullptr, ne, 32, bits, ln.sort_tmp->p);
@@ -1200,9 +1324,19 @@ public:
     }
     void conduction_sparse_apply()
     {
-        if (cond_ne > 0)
-            be::launch(st, cond_ne, ConductionApply{(int64_t)cond_ne, cond_entries[cond_sorted].p, cbody.p, temp.p, mass.p,
-                                                    cfg.heat_coeff, cdelta.p});
+        if (cond_ne > 0) {
+            ConductionApply a;
+            a.n_entries = (int64_t)cond_ne; a.entries = cond_entries[cond_sorted].p; a.body = cbody.p; a.temp = temp.p;
+            a.mass = mass.p; a.heat_coeff = cfg.heat_coeff; a.delta = cdelta.p;
+            a.slot_state = nullptr; a.moved = nullptr; a.slot_delta = nullptr;
+            if (deferred) {
+                // (the touched slots' temperatures are in slot_state, the sums go to slot_delta for the export)
+                slot_delta.ensure(cond_ne);
+                a.slot_state = slot_state.p; a.moved = moved.p; a.slot_delta = slot_delta.p;
+            }
+            be::launch(st, cond_ne, a);
+        }
+        if (deferred) return;
         if (cfg.debug) {
             delta_dbg.ensure((size_t)n);
             be::copy_d2d(st, delta_dbg.p, cdelta.p, (size_t)n * 8);
@@ -1342,8 +1476,7 @@ public:
         // persistent waves from being placed, and the step got 4 % slower)
         be::delay(st2, 40);
         build_grid(st2, sort_tmp2);
-        // (in a sharded step the caller may ask for the count pass of its own slab instead: stage_detect)
-        if ((cfg.stage_mask & kStageCollisions) && !sharded_step) {
+        if (cfg.stage_mask & kStageCollisions) {
             detect_count(st2, scan_tmp2, counters2.p, true);
             predetected = true;
         }
@@ -1385,6 +1518,8 @@ public:
         totals_pending = false;
         walk_in_flight = false;
         detect_prune = true;
+        deferred = false;
+        applied_deltas = false;
         be::wide_groups() = true;
     }
     void no_collisions()
@@ -1430,111 +1565,270 @@ public:
         timer.mark(st, 8);
     }
 
-    // ---- the same step cut at its exchange points, for one simulation sharded over
-    // several GPUs: every rank holds the full state and builds the same grid and tree;
-    // the walk and the conduction sweep run on a rank's share of sorted particles /
-    // grid slots and their outputs are all-gathered by the caller between stages.
+    // ---- The same step cut at its exchange points, for one simulation split over several
+    // GPUs.  Every rank holds the full state and builds the same tree; the walk runs on a
+    // rank's share of the sorted particles, the collision stage (and conduction with it) on
+    // the band of grid rows the rank owns plus halo rows, and the caller exchanges the
+    // results between the stages (accelerations; the bands' export blocks).
     void stage_build()
     {
         begin_step();
         sharded_step = true;
+        deferred = true;
         timer.mark(st, 0);
         keys_and_drift(true);
         timer.mark(st, 1);
-        const bool side = cfg.overlap != 0 && n > 0;
-        if (!side) { build_grid(); timer.mark(st, 2); }
-        else timer.same_as(2, 1);
+        timer.same_as(2, 1);
         build_tree();
         timer.mark(st, 3);
     }
     void stage_gravity(int64_t lo, int64_t hi, vec2* acc_sorted)
     {
         if (lo < 0 || hi > n || lo > hi) throw std::invalid_argument("psim: bad sorted range");
-        const bool side = cfg.overlap != 0 && n > 0;
         // (mark 3, recorded when stage_build finished the tree, releases the side stream)
         gravity_range(lo, hi, acc_sorted, true);
         timer.mark(st, 4);
-        walk_in_flight = true;
-        be::wide_groups() = false;
-        if (side) start_side_work();
+        walk_in_flight = hi > lo;
+        be::wide_groups() = !walk_in_flight;
     }
-    // Optional, between stage_gravity and stage_kick_collide: the position half of the
-    // collision stage.  It waits for small readbacks of its own stream, so a caller that
-    // has an exchange of accelerations to do starts that exchange first and calls this
-    // while it is in flight.  Without the call, stage_kick_collide does the work itself.
-    void stage_settle_positions() { settle_positions(); }
-    // Optional, after stage_gravity: contact detection of sweep 0 for the grid slots
-    // [k_lo, k_hi) only.  Every rank holds all positions, so a slab needs no halo exchange;
-    // the caller gathers the ranks' key lists and hands the whole list to
-    // stage_settle_positions_from().  out4 = {contacts found, candidate pairs examined, pairs
-    // at squared distance zero, keys written (0 if `cap` was too small: call again with
-    // room for out4[0] keys)}.  keys_out: device pointer.
-    void stage_detect(int64_t k_lo, int64_t k_hi, uint64_t* keys_out, int64_t cap, int64_t out4[4])
+    // The half of the collision stage that needs no velocities, for the band of grid rows
+    // [row_lo, row_hi) of which [own_lo, own_hi) are this rank's own: grid of the band,
+    // contact detection, contact list and pushed-apart positions.  While a walk submitted by
+    // stage_gravity is in flight it runs on the side stream underneath it (it waits for small
+    // readbacks of that stream, so a caller with an exchange of accelerations to do starts
+    // that exchange first).
+    void stage_slab_positions(const Band& b)
     {
-        out4[0] = out4[1] = out4[2] = out4[3] = 0;
-        if (k_lo < 0 || k_hi > n || k_lo > k_hi || (k_hi > k_lo && (k_lo & 3)))
-            throw std::invalid_argument("psim: bad slot range");
-        if (!(cfg.stage_mask & kStageCollisions) || n == 0 || cfg.solver_iterations <= 0) return;
-        Lane ln = side_running ? side_lane() : main_lane();
-        detect_count(ln.s, *ln.scan_tmp, ln.ctr, ln.small_groups, k_lo, k_hi);
-        uint32_t four[4];
-        readback_on(ln, four, ln.ctr, 16);
-        set_slot_bits(four[2]);
-        out4[0] = four[0]; out4[1] = four[1]; out4[2] = four[3];
-        if (four[0] > 0 && (int64_t)four[0] <= cap && k_hi > k_lo) {
-            GridView g = grid_view();
-            ContactDetect d;
-            d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
-            d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p;
-            d.first_pair = reinterpret_cast<uint32_t*>(first_key.p); d.coincident_counter = nullptr; d.cand_counter = nullptr;
-            d.out_keys = keys_out; d.write_pass = 1;
-            be::launch(ln.s, k_hi - k_lo, d);
-            out4[3] = four[0];
+        if (!sharded_step) throw std::runtime_error("psim: stage_slab_positions outside a staged step");
+        deferred = true;
+        positions_settled = false;
+        moved_valid = false;
+        predetected = false;
+        detect_prune = true;
+        n_moved = 0; n_coincident = 0; cond_ne = 0; cond_pairs_ready = false;
+        seam_n[0] = seam_n[1] = 0;
+        own_slots = 0;
+        band = b;
+        if (b.row_lo < 0 || b.row_hi > cfg.grid_h || b.row_lo > b.row_hi || b.own_lo < b.row_lo || b.own_hi > b.row_hi || b.own_lo > b.own_hi)
+            throw std::invalid_argument("psim: bad band of grid rows");
+        if (!(cfg.stage_mask & kStageCollisions) || n == 0 || b.row_lo == b.row_hi) {
+            ns = 0;
+            band_partial = true;
+            full_grid_valid = false;
+            no_collisions();
+            positions_settled = true;
+            return;
         }
-        be::sync(ln.s);      // the caller's exchange reads keys_out from another stream
+        refresh_groups();
+        const bool side = cfg.overlap != 0 && walk_in_flight;
+        Lane ln = side ? side_lane() : main_lane();
+        if (side) {
+            be::stream_wait(st2, ev_release());
+            be::delay(st2, 40);      // (the walk's persistent waves take their slots first, see start_side_work)
+            side_running = true;
+        }
+        build_grid_band(ln, b);
+        collisions_positions(ln);
+        if (side) be::event_record(ev_side, st2);
     }
-    void stage_settle_positions_from(const uint64_t* keys, int64_t n0, int64_t candidates, int64_t coincident)
+    // second half-kick from the gathered accelerations (sorted order)
+    void stage_kick(const vec2* acc_sorted)
     {
-        if (n0 < 0 || n0 > 0x7fffffffLL || (n0 > 0 && !keys)) throw std::invalid_argument("psim: bad contact key list");
-        ext_keys = keys; ext_given = true;
-        ext_n0 = n0; ext_candidates = candidates; ext_coincident = coincident;
-        settle_positions();
-        ext_given = false;
-    }
-    void stage_kick_collide(const vec2* acc_sorted)
-    {
+        if (!sharded_step) throw std::runtime_error("psim: stage_kick outside a staged step");
         be::launch(st, n, ScatterSorted{n, perm[sorted_key].p, walk_order(), acc_sorted, acc2.p});
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});
         acc.swap(acc2);
-        settle_positions();
+    }
+    // Velocity half of the band's collision stage and its conduction sums, after stage_kick.
+    // Everything stays in slot order; slab_export() writes the block the other ranks need.
+    void stage_slab_finish()
+    {
+        if (!sharded_step || !deferred) throw std::runtime_error("psim: stage_slab_finish outside a staged step");
         join_side_work();
-        settle_positions(true);
         timer.mark(st, 5);
-        if (cfg.stage_mask & kStageCollisions) collisions_velocities();
-        else no_collisions();
+        if ((cfg.stage_mask & kStageCollisions) && ns > 0) collisions_velocities();
+        else moved_valid = (cfg.stage_mask & kStageCollisions) != 0;
         timer.mark(st, 6);
-        sharded_step = false;
+        if (sparse_conduction_possible()) conduction_sparse_apply();
     }
-    // When conduction can run around the touched slots only it is cheap and every rank does
-    // all of it in stage_finish (this call then leaves temp_slots alone); otherwise the full
-    // sweep is split by slot range.  All ranks take the same branch: it depends on state only.
-    void stage_conduction(int64_t lo, int64_t hi, double* temp_slots)
+    // Writes the band's block: header, then the state of the touched slots of the owned rows,
+    // the conduction sums of the targets in the owned rows, the two seams' contact records.
+    // Returns the number of words the block needs; when that exceeds cap_words only the
+    // header is written (marked incomplete) and the call can be repeated with more room.
+    int64_t slab_export(uint64_t* out, int64_t cap_words)
     {
-        if (lo < 0 || hi > n || lo > hi) throw std::invalid_argument("psim: bad slot range");
-        if (!sparse_conduction_possible()) conduction_and_cooling(lo, hi, temp_slots);
+        if (!sharded_step || !deferred) throw std::runtime_error("psim: slab_export outside a staged step");
+        if (!out || cap_words < kExportHeaderWords) throw std::invalid_argument("psim: export block smaller than its header");
+        const bool with_deltas = sparse_conduction_possible() && cond_ne > 0;
+        uint32_t n_state = 0, n_delta = 0;
+        const size_t tmp_n = (size_t)(n_moved > cond_ne ? n_moved : cond_ne) + 1;
+        bflag.ensure(2 * tmp_n); bat.ensure(2 * tmp_n);
+        scan_tmp.ensure_zero(st, be::scan_temp_words(tmp_n));
+        be::dev_memset(st, step_words.p + 12, 0, 16);
+        if (n_moved > 0) {
+            be::launch(st, n_moved, ExportStateFlag{(int64_t)n_moved, moved_list.p, cbody.p, band.own_lo, band.own_hi, bflag.p});
+            be::exclusive_scan_u32(st, bflag.p, bat.p, n_moved, scan_tmp.p, step_words.p + 12);
+        }
+        if (with_deltas) {
+            be::launch(st, cond_ne, ExportDeltaFlag{(int64_t)cond_ne, cond_entries[cond_sorted].p, cbody.p, band.own_lo, band.own_hi,
+                                                    bflag.p + tmp_n});
+            be::exclusive_scan_u32(st, bflag.p + tmp_n, bat.p + tmp_n, cond_ne, scan_tmp.p, step_words.p + 13);
+        }
+        if (ns > 0) {
+            // slots of the owned rows: the band's cells are row-major, so they are one run of slots
+            be::launch(st, 1, OwnedSlots{offsets.p, (int64_t)(band.own_lo - band.row_lo) * cfg.grid_w,
+                                         (int64_t)(band.own_hi - band.row_lo) * cfg.grid_w, step_words.p + 14});
+        }
+        {
+            struct { double t[3]; uint32_t pad[2]; uint32_t pad2[4]; uint32_t c[4]; } back;
+            static_assert(sizeof(back) == 64, "layout of the step words");
+            readback(&back, step_words.p, 64, true);
+            if (totals_pending) {
+                coll_totals[0] += back.t[0]; coll_totals[1] += back.t[1]; coll_totals[2] += back.t[2];
+                totals_pending = false;
+            }
+            n_state = back.c[0]; n_delta = back.c[1]; own_slots = back.c[2];
+        }
+        const int64_t need = kExportHeaderWords + (int64_t)kExportStateWords * n_state + (int64_t)kExportDeltaWords * n_delta +
+                             (int64_t)kExportSeamWords * (seam_n[0] + seam_n[1]);
+        const bool fits = need <= cap_words;
+        ExportHeader h;
+        for (int i = 0; i < kExportHeaderWords; ++i) h.words[i] = 0;
+        h.words[0] = n_state; h.words[1] = n_delta; h.words[2] = (uint64_t)seam_n[0]; h.words[3] = (uint64_t)seam_n[1];
+        h.words[4] = (uint64_t)n_contacts; h.words[5] = (uint64_t)n_candidates; h.words[6] = n_coincident;
+        h.words[7] = (uint64_t)own_slots;
+        h.words[8] = f64_bits(coll_totals[0]); h.words[9] = f64_bits(coll_totals[1]); h.words[10] = f64_bits(coll_totals[2]);
+        h.words[11] = (uint64_t)need; h.words[12] = (uint64_t)solver_fixpoint_iters; h.words[13] = (uint64_t)solver_rounds;
+        h.words[14] = (uint64_t)(uint32_t)band.own_lo | ((uint64_t)(uint32_t)band.own_hi << 32);
+        h.words[15] = fits ? 1u : 0u;
+        h.words[16] = (uint64_t)n;
+        h.out = out;
+        be::launch(st, kExportHeaderWords, h);
+        if (fits) {
+            uint64_t* at = out + kExportHeaderWords;
+            if (n_state > 0)
+                be::launch(st, n_moved, ExportStateWrite{(int64_t)n_moved, moved_list.p, bflag.p, bat.p, cbody.p, slot_state.p, at});
+            at += (size_t)kExportStateWords * n_state;
+            if (n_delta > 0)
+                be::launch(st, cond_ne, ExportDeltaWrite{(int64_t)cond_ne, cond_entries[cond_sorted].p, bflag.p + tmp_n, bat.p + tmp_n,
+                                                         cbody.p, slot_delta.p, at});
+            at += (size_t)kExportDeltaWords * n_delta;
+            for (int k = 0; k < 2; ++k) {
+                if (seam_n[k] > 0)
+                    be::launch(st, seam_n[k] * kExportSeamWords, CopyWords{seam_n[k] * kExportSeamWords, seam_rec[k].p, at});
+                at += (size_t)kExportSeamWords * (size_t)seam_n[k];
+            }
+        }
+        be::sync(st);       // (the caller's exchange reads the block from another stream)
+        return need;
+    }
+    // The ranks' blocks, side by side (`world` blocks of block_words words, rank order, device
+    // memory).  Returns 0 when every pair of neighbouring ranks recorded the same contacts along
+    // their seam: all blocks' results are then written to the state arrays.  1: some seam's
+    // records differ -- nothing was applied, the caller runs stage_fallback().  2: some block
+    // was too small (*needed = the largest need) -- export again with room and call again.
+    int stage_apply(const uint64_t* blocks, int world, int64_t block_words, int64_t* own_slots_out, int64_t* needed)
+    {
+        if (!sharded_step || !deferred) throw std::runtime_error("psim: stage_apply outside a staged step");
+        if (!blocks || world < 1 || world > 4096 || block_words < kExportHeaderWords) throw std::invalid_argument("psim: bad export blocks");
+        std::vector<uint64_t> hd((size_t)world * kExportHeaderWords);
+        hdr_dev.ensure(hd.size());
+        be::launch(st, (int64_t)hd.size(), GatherHeaders{world, block_words, blocks, hdr_dev.p});
+        be::copy_d2h(st, hd.data(), hdr_dev.p, hd.size() * 8);
+        be::sync(st);
+        auto H = [&](int r, int w) { return hd[(size_t)r * kExportHeaderWords + w]; };
+        int64_t most = 0;
+        bool complete = true;
+        for (int r = 0; r < world; ++r) {
+            if (H(r, 16) != (uint64_t)n) throw std::runtime_error("psim: export block of another step or particle count");
+            if ((int64_t)H(r, 11) > most) most = (int64_t)H(r, 11);
+            if (H(r, 15) != 1) complete = false;
+            if (own_slots_out) own_slots_out[r] = (int64_t)H(r, 7);
+        }
+        if (needed) *needed = most;
+        if (!complete) return 2;
+        auto section = [&](int r, int which) {
+            const uint64_t* p = blocks + (size_t)r * block_words + kExportHeaderWords;
+            if (which > 0) p += (size_t)kExportStateWords * H(r, 0);
+            if (which > 1) p += (size_t)kExportDeltaWords * H(r, 1);
+            if (which > 2) p += (size_t)kExportSeamWords * H(r, 2);
+            return p;
+        };
+        // ---- seams: the upper seam of a rank against the lower seam of the next rank that owns rows
+        bool agree = true;
+        be::dev_memset(st, step_words.p + 12, 0, 4);
+        int prev = -1;
+        for (int r = 0; r < world; ++r) {
+            const int32_t lo = (int32_t)(uint32_t)H(r, 14), hi = (int32_t)(uint32_t)(H(r, 14) >> 32);
+            if (hi <= lo) continue;          // owns no rows
+            if (prev >= 0) {
+                const int32_t phi = (int32_t)(uint32_t)(H(prev, 14) >> 32);
+                if (phi != lo) throw std::invalid_argument("psim: the ranks' bands do not tile the grid rows");
+                const uint64_t na = H(prev, 3), nb = H(r, 2);
+                if (na != nb) agree = false;
+                else if (na > 0)
+                    be::launch(st, (int64_t)(na * kExportSeamWords), CompareKeys{(int64_t)(na * kExportSeamWords), section(prev, 3),
+                                                                                 section(r, 2), step_words.p + 12});
+            }
+            prev = r;
+        }
+        if (agree) agree = read_u32(step_words.p + 12) == 0;
+        if (!agree) { ++slab_fallbacks; return 1; }
+        // ---- apply
+        double tot[3] = {0, 0, 0};
+        int64_t contacts = 0, candidates = 0, coincident = 0;
+        cdelta.ensure((size_t)n);
+        if (n > 0) be::dev_memset(st, cdelta.p, 0, (size_t)n * 8);
+        for (int r = 0; r < world; ++r) {
+            if (H(r, 0) > 0) be::launch(st, (int64_t)H(r, 0), ApplyState{(int64_t)H(r, 0), section(r, 0), pos.p, vel.p, temp.p});
+            coincident += (int64_t)H(r, 6);
+        }
+        for (int r = 0; r < world && coincident == 0; ++r)
+            if (H(r, 1) > 0) be::launch(st, (int64_t)H(r, 1), ApplyDelta{(int64_t)H(r, 1), section(r, 1), cdelta.p});
+        for (int r = 0; r < world; ++r) {
+            tot[0] += bits_f64(H(r, 8)); tot[1] += bits_f64(H(r, 9)); tot[2] += bits_f64(H(r, 10));
+            contacts += (int64_t)H(r, 4); candidates += (int64_t)H(r, 5);
+        }
+        coll_totals[0] = tot[0]; coll_totals[1] = tot[1]; coll_totals[2] = tot[2];
+        n_contacts = contacts; n_candidates = candidates; n_coincident = (uint32_t)(coincident > 0xffffffffll ? 0xffffffffll : coincident);
+        moved_valid = (cfg.stage_mask & kStageCollisions) != 0;
+        deferred = false;
+        applied_deltas = true;
+        return 0;
+    }
+    bool applied_deltas = false;       // cdelta holds the step's conduction sums, from the ranks' blocks
+    // After a seam disagreement: the whole collision stage again on the whole grid, on every
+    // rank alike (state arrays written directly, as in step()).
+    void stage_fallback()
+    {
+        if (!sharded_step) throw std::runtime_error("psim: stage_fallback outside a staged step");
+        deferred = false;
+        applied_deltas = false;
+        positions_settled = false;
+        moved_valid = false;
+        predetected = false;
+        detect_prune = true;
+        totals_pending = false;
+        build_grid(st, sort_tmp);
+        if (cfg.stage_mask & kStageCollisions) collisions();
+        else no_collisions();
+    }
+    void stage_finish()
+    {
+        if (!sharded_step || deferred) throw std::runtime_error("psim: stage_finish before stage_apply / stage_fallback");
+        const bool sparse = sparse_conduction_possible();
+        if (sparse) {
+            if (!applied_deltas) conduction_sparse_apply();
+        } else {
+            if (n > 0 && (cfg.stage_mask & kStageConduction)) ensure_full_grid();
+            conduction_and_cooling();
+        }
         timer.mark(st, 7);
-    }
-    void stage_finish(const double* temp_slots)
-    {
-        bool cond = (cfg.stage_mask & kStageConduction) != 0;
-        bool cool = (cfg.stage_mask & kStageCooling) != 0 && cfg.damping > 0;
-        bool sparse = sparse_conduction_possible();
-        if (sparse) conduction_sparse_apply();
-        else if (n > 0 && cond) be::launch(st, n, ScatterSlots{n, cbody.p, temp_slots, temp.p});
-        else if (n > 0 && cool) be::launch(st, n, Cooling{n, temp.p, 1.0 - cfg.damping});
         uint32_t nb = walls_and_flags(sparse);
-        if (nb > 0) explosions(nb);
+        if (nb > 0) { ensure_full_grid(); explosions(nb); }
         timer.mark(st, 8);
+        sharded_step = false;
+        applied_deltas = false;
     }
 
     // particle_system.py:765-804 (+ total momentum)

@@ -24,10 +24,10 @@ EXPORTS = [
     "psim_collision_stats", "psim_counts", "psim_explosion_events", "psim_walk_counts",
     "psim_debug_size", "psim_debug_fetch", "psim_selftest", "psim_stage_times",
     "psim_last_error", "psim_version",
-    "psim_stage_build", "psim_stage_gravity", "psim_stage_kick_collide", "psim_stage_conduction",
-    "psim_stage_finish", "psim_brute_force_gravity", "psim_render_feed", "psim_pair_potential_energy",
-    "psim_stage_conduction_exchanges", "psim_stage_settle_positions", "psim_time_walk",
-    "psim_stage_detect", "psim_stage_settle_positions_from", "psim_pair_potential_energy_noalloc",
+    "psim_stage_build", "psim_stage_gravity", "psim_stage_slab_positions", "psim_stage_kick",
+    "psim_stage_slab_finish", "psim_stage_slab_export", "psim_stage_apply", "psim_stage_fallback",
+    "psim_stage_finish", "psim_stage_stats", "psim_brute_force_gravity", "psim_render_feed",
+    "psim_pair_potential_energy", "psim_time_walk", "psim_pair_potential_energy_noalloc",
 ]
 
 
@@ -103,14 +103,15 @@ def load(path=None):
     L.psim_stage_times.argtypes = [vp, c_dp]
     L.psim_stage_build.argtypes = [vp]
     L.psim_stage_gravity.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp]
-    L.psim_stage_kick_collide.argtypes = [vp, vp]
-    L.psim_stage_settle_positions.argtypes = [vp]
-    L.psim_stage_detect.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
-    L.psim_stage_settle_positions_from.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    L.psim_stage_slab_positions.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.psim_stage_kick.argtypes = [vp, vp]
+    L.psim_stage_slab_finish.argtypes = [vp]
+    L.psim_stage_slab_export.argtypes = [vp, vp, ctypes.c_int64, c_ip]
+    L.psim_stage_apply.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), c_ip, c_ip]
+    L.psim_stage_fallback.argtypes = [vp]
+    L.psim_stage_finish.argtypes = [vp]
+    L.psim_stage_stats.argtypes = [vp, c_ip]
     L.psim_time_walk.argtypes = [vp, ctypes.c_int32, ctypes.c_double, c_dp]
-    L.psim_stage_conduction.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp]
-    L.psim_stage_finish.argtypes = [vp, vp]
-    L.psim_stage_conduction_exchanges.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.psim_brute_force_gravity.argtypes = [vp, vp, c_dp]
     L.psim_render_feed.argtypes = [vp, vp, vp]
     L.psim_pair_potential_energy.argtypes = [vp, c_dp]

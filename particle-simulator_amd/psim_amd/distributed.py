@@ -1,29 +1,44 @@
-"""One simulation sharded over the GPUs of a node: one process per GPU,
+"""One simulation split over the GPUs of a node: one process per GPU,
 `torch.distributed` (backend "nccl" = RCCL over xGMI; "gloo" on CPU for tests).
 
 The reference is single-process, so nothing here has a counterpart in it.  Every
-rank holds the full particle state and rebuilds the same grid and tree (the
-builds are deterministic, so no broadcast is needed).  The two stages that
-dominate the step are split by range and their outputs exchanged:
+rank holds the full particle state and rebuilds the same tree (the build is
+deterministic, so no broadcast is needed).  The two stages that dominate the step
+are split and their outputs exchanged:
 
-  * gravity: rank r walks the tree for a contiguous range of Morton-sorted
-    target particles; accelerations are all-gathered in sorted order (16 B per
-    particle) -- one all-gather per step;
-  * contact detection: rank r sweeps a contiguous range of grid slots (cells are
-    row-major, so that is a slab of the domain; every rank holds all positions,
-    so a slab needs no halo) and the ranks' contact key lists are all-gathered
-    (8 B per contact, a few per cent of the particle count); the contact solver
-    itself runs on every rank on the gathered list;
-  * conduction + cooling: when the step needs the full neighbour sweep, rank r
-    sweeps a contiguous range of grid slots (whole runs of row-major cells, i.e. a
-    spatial slab) and temperatures are all-gathered in slot order (8 B per
-    particle); normally conduction only involves the few slots the contacts
-    touched, every rank does all of it and nothing is exchanged.
+  * gravity: rank r walks the tree for a contiguous range of Morton-sorted target
+    particles; accelerations are all-gathered in sorted order (16 B per particle);
+  * collisions + conduction: rank r owns a slab of the domain -- a band of whole
+    grid rows (cells are row-major, particle_system.py:749) -- and solves it together
+    with `halo_rows` rows on either side, on a grid of that band only: cell sort,
+    contact detection, the exact Gauss-Seidel contact solver, conduction sums.  It
+    exports the results of its OWN rows (state of the touched particles, conduction
+    sums) and, for each seam, a record of every contact it saw in the two rows along
+    it.  The blocks are all-gathered; when both ranks along every seam recorded the
+    same contacts, every rank's view of its neighbour's rows was the true one, the
+    owned results together are exactly the sequential sweep's, and every rank applies
+    all of them.  When a seam disagrees (a chain of dependent contacts longer than the
+    halo reached it) every rank runs the step's collision stage again on the whole
+    grid -- always exact, sharded whenever the halo suffices.
 
-Each element is computed by exactly one rank with the same arithmetic as the
-single-GPU step, so the result is bit-identical for any number of ranks.
+Explosions (particle_system.py:651-730) and the full conduction sweep that a pair of
+exactly coinciding particles forces are done by every rank alike on the whole grid,
+built only in the steps that need it.  The result is bit-identical to the unsharded
+step for any number of ranks.
+
+The per-step exchange allocates nothing: every buffer (accelerations, the rank's
+block, the gathered blocks, and with the "host" transport their page-locked host
+twins) exists before the first step and only grows, on all ranks together, when a
+block did not fit.
+
+`emulate=(world, rank)` plays all `world` ranks in turn in ONE process on one
+device and times the share of `rank` alone (bench.py --emulate-rank): what one GPU
+of an N-GPU job computes per step, and the bytes it exchanges, measured without N
+GPUs.  It calls exactly the entry points with exactly the ranges the real ranks use.
 """
+import contextlib
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -33,6 +48,7 @@ from . import _capi
 from .particle_system import ParticleSystem
 
 _ALIGN = 256
+HEADER_WORDS = 32
 
 
 def shard_range(n, rank, world):
@@ -44,118 +60,250 @@ def shard_range(n, rank, world):
     return lo, hi, per
 
 
+def balanced_rows(row_counts, world):
+    """Row boundaries B[0..world] (B[0] = 0, B[world] = number of rows) that give every rank
+    about the same number of particles: rank r owns rows [B[r], B[r+1])."""
+    rows = len(row_counts)
+    cum = np.concatenate(([0], np.cumsum(np.asarray(row_counts, dtype=np.int64))))
+    total = int(cum[-1])
+    bounds = [0]
+    for r in range(1, world):
+        want = (total * r) // world
+        # first row boundary at which at least `want` particles lie before it
+        b = int(np.searchsorted(cum, want, side="left"))
+        b = max(bounds[-1], min(b, rows))
+        bounds.append(b)
+    bounds.append(rows)
+    return bounds
+
+
 class ShardedParticleSystem(ParticleSystem):
-    """`ParticleSystem` whose `update()` splits the walk and the conduction sweep
-    over the ranks of `group`.  All ranks must construct it with the same
+    """`ParticleSystem` whose `update()` splits the walk over ranges of sorted particles and the
+    collision stage over slabs of grid rows.  All ranks must construct it with the same
     arguments and call `update()` together."""
 
-    def __init__(self, *args, group=None, **kw):
+    def __init__(self, *args, group=None, halo_rows=2, emulate=None, transport=None, **kw):
         super().__init__(*args, **kw)
         self._group = group
-        self._rank = dist.get_rank(group)
-        self._world = dist.get_world_size(group)
+        self._emulate = emulate
+        if emulate is not None:
+            self._world, self._rank = int(emulate[0]), int(emulate[1])
+            if not (0 <= self._rank < self._world):
+                raise ValueError("emulate=(world, rank): rank out of range")
+        else:
+            self._rank = dist.get_rank(group)
+            self._world = dist.get_world_size(group)
         on_gpu = kw.get("library") is None
         self._tdev = torch.device("cuda", self._device) if on_gpu else torch.device("cpu")
+        # how the exchanged buffers travel: "device" = the collective works on the device
+        # tensors (RCCL); "host" = through page-locked host copies (any backend that moves CPU
+        # tensors: several ranks sharing one GPU over gloo); "cpu" = the buffers are host memory
+        # already (the test-only host-loop build)
+        if transport is None:
+            if not on_gpu:
+                transport = "cpu"
+            elif emulate is not None or self._world == 1 or dist.get_backend(group) == "nccl":
+                transport = "device"
+            else:
+                transport = "host"
+        self._transport = transport
+        self._halo = max(2, int(halo_rows))
         n = self.num_particles
-        _, _, per = shard_range(n, 0, self._world)
-        self._acc = torch.zeros((per * self._world, 2), dtype=torch.float64, device=self._tdev)
-        self._tmp = torch.zeros((per * self._world,), dtype=torch.float64, device=self._tdev)
-        self._keys = torch.zeros((max(4096, per // 8),), dtype=torch.int64, device=self._tdev)
-        self._cat_keys = None
-        self._all_keys = None
-        # the small exchanges of the contact lists run on a stream of their own, so that they
-        # are not ordered behind the walk (which is on the default stream)
-        self._side = torch.cuda.Stream(device=self._tdev) if self._tdev.type == "cuda" else None
+        W = self._world
+        _, _, per = shard_range(n, 0, W)
+        self._acc = torch.zeros((per * W, 2), dtype=torch.float64, device=self._tdev)
+        self._shard = torch.zeros((per, 2), dtype=torch.float64, device=self._tdev)
+        self._block_words = 0
+        self._blocks = self._block = self._blocks_h = self._block_h = None
+        self._acc_h = self._shard_h = None
+        if transport == "host":
+            self._acc_h = torch.zeros((per * W, 2), dtype=torch.float64, pin_memory=True)
+            self._shard_h = torch.zeros((per, 2), dtype=torch.float64, pin_memory=True)
+        self._alloc_blocks(HEADER_WORDS + 4096 + per)
+        self._own_slots = (ctypes.c_int64 * W)()
+        # rows of the grid per rank, balanced by particle count (all ranks hold the same state)
+        y = self._host["positions"][:, 1]
+        row = np.clip((y / self.cell_size).astype(np.int64), 0, self.grid_height - 1)
+        self._row_bounds = balanced_rows(np.bincount(row, minlength=self.grid_height), W)
+        self.fallbacks = 0
+        self.emulated_ms = {}
+        self.exchange_bytes = {}
 
-    def _detect_and_gather(self, lo, hi):
-        """contact detection of the first collision sweep on this rank's slab of grid slots,
-        then the ranks' key lists gathered -> (tensor of all keys, contacts, candidates,
-        coincident pairs).
+    # ------------------------------------------------------------------ buffers
+    def _alloc_blocks(self, words):
+        """(all ranks call this with the same size)"""
+        W = self._world
+        self._block_words = int(words)
+        self._block = torch.zeros((self._block_words,), dtype=torch.int64, device=self._tdev)
+        self._blocks = torch.zeros((W * self._block_words,), dtype=torch.int64, device=self._tdev)
+        if self._transport == "host":
+            self._block_h = torch.zeros((self._block_words,), dtype=torch.int64, pin_memory=True)
+            self._blocks_h = torch.zeros((W * self._block_words,), dtype=torch.int64, pin_memory=True)
 
-        One collective: every rank sends a block of `cap` words -- three counters (contacts,
-        candidates, coincident pairs), then its keys -- and reads the counters of all blocks
-        back once.  A rank whose list did not fit makes everybody grow the block and repeat
-        (the counters tell all ranks the same thing)."""
-        L, ctx = self._lib, self._ctx
-        out = (ctypes.c_int64 * 4)()
-        import contextlib
-        side = torch.cuda.stream(self._side) if self._side is not None else contextlib.nullcontext()
-        while True:
-            cap = self._keys.numel() - 3
-            _capi.check(L, L.psim_stage_detect(ctx, lo, hi, ctypes.c_void_p(self._keys.data_ptr() + 24), cap, out))
-            mine = [int(out[0]), int(out[1]), int(out[2])]
-            if self._world == 1:
-                if out[3] == out[0]:
-                    return self._keys[3:], mine[0], mine[1], mine[2]
-                # (no fill: the library writes the keys on a stream of its own, and a fill queued
-                # on this one behind the walk would land on top of them later)
-                self._keys = torch.empty((mine[0] + mine[0] // 4 + 4096,), dtype=torch.int64, device=self._tdev)
-                continue
-            with side:
-                self._keys[:3] = torch.tensor(mine, dtype=torch.int64).to(self._tdev, non_blocking=False)
-                block = self._keys.numel()
-                if self._all_keys is None or self._all_keys.numel() != self._world * block:
-                    self._all_keys = torch.empty((self._world * block,), dtype=torch.int64, device=self._tdev)
-                dist.all_gather_into_tensor(self._all_keys, self._keys, group=self._group)
-                blocks = self._all_keys.view(self._world, block)
-                every = blocks[:, :3].cpu()
-                n_each = [int(v) for v in every[:, 0]]
-                most = max(n_each)
-                if most > cap:
-                    self._keys = torch.empty((most + most // 4 + 4096,), dtype=torch.int64, device=self._tdev)
-                    continue
-                total = sum(n_each)
-                keys = self._keys
-                if total > 0:
-                    keys = torch.cat([blocks[r, 3: 3 + n_each[r]] for r in range(self._world)])
-                    if self._side is not None:
-                        self._side.synchronize()
-                self._cat_keys = keys      # (kept alive while the library copies from it)
-            return keys, total, int(every[:, 1].sum()), int(every[:, 2].sum())
+    def _sync(self):
+        if self._tdev.type == "cuda":
+            torch.cuda.synchronize(self._tdev)
 
-    def _gather(self, buf, per, async_op=False):
-        """in-place all-gather of the ranks' equal shards of buf[: per * world];
-        with async_op the collective is only started and its handle returned"""
-        if self._world == 1:
+    def band_of(self, rank):
+        """(row_lo, row_hi, own_lo, own_hi) of `rank`: its own rows and the halo around them"""
+        lo, hi = self._row_bounds[rank], self._row_bounds[rank + 1]
+        if hi <= lo:
+            return lo, lo, lo, lo
+        return max(0, lo - self._halo), min(self.grid_height, hi + self._halo), lo, hi
+
+    def _rebalance(self):
+        """next step's rows from this step's per-rank populations (the same numbers on every
+        rank, so the same rows): each rank's rows are taken as evenly populated"""
+        W = self._world
+        counts = [int(v) for v in self._own_slots]
+        total = sum(counts)
+        if W == 1 or total == 0:
+            return
+        if max(counts) * W <= total * 1.08:
+            return
+        per_row = np.zeros(self.grid_height, dtype=np.int64)
+        for r in range(W):
+            lo, hi = self._row_bounds[r], self._row_bounds[r + 1]
+            if hi > lo:
+                base, extra = divmod(counts[r], hi - lo)
+                per_row[lo:hi] = base
+                per_row[lo:lo + extra] += 1
+        self._row_bounds = balanced_rows(per_row, W)
+
+    # ------------------------------------------------------------------ exchanges
+    def _gather_acc_start(self, per):
+        """all-gather of the ranks' equal shards of self._acc; returns a handle to wait for
+        (device transport) or None (done, or nothing to do)"""
+        W = self._world
+        if W == 1 or self._emulate is not None:
             return None
-        flat = buf[: per * self._world]
+        flat = self._acc[: per * W]
         mine = flat[self._rank * per:(self._rank + 1) * per]
-        return dist.all_gather_into_tensor(flat, mine.clone(), group=self._group, async_op=async_op)
+        if self._transport == "host":
+            # (the walk and this copy are on the device's default stream)
+            self._shard_h[:per].copy_(mine, non_blocking=False)
+            dist.all_gather_into_tensor(self._acc_h[: per * W], self._shard_h[:per], group=self._group)
+            flat.copy_(self._acc_h[: per * W], non_blocking=False)
+            return None
+        self._shard[:per].copy_(mine)
+        return dist.all_gather_into_tensor(flat, self._shard[:per], group=self._group, async_op=self._transport == "device")
+
+    def _gather_blocks(self):
+        W = self._world
+        if self._emulate is not None:
+            return
+        if W == 1:
+            self._blocks.copy_(self._block)
+            return
+        if self._transport == "host":
+            self._block_h.copy_(self._block, non_blocking=False)
+            dist.all_gather_into_tensor(self._blocks_h, self._block_h, group=self._group)
+            self._blocks.copy_(self._blocks_h, non_blocking=False)
+            return
+        dist.all_gather_into_tensor(self._blocks, self._block, group=self._group)
+        self._sync()
+
+    # ------------------------------------------------------------------ pieces of a step
+    def _export(self, rank):
+        """the current band's block -> self._block (real ranks) / its place in self._blocks (emulation)"""
+        L, ctx = self._lib, self._ctx
+        need = ctypes.c_int64(0)
+        if self._emulate is not None:
+            ptr = self._blocks.data_ptr() + 8 * rank * self._block_words
+        else:
+            ptr = self._block.data_ptr()
+        _capi.check(L, L.psim_stage_slab_export(ctx, ctypes.c_void_p(ptr), self._block_words, ctypes.byref(need)))
+        return int(need.value)
+
+    def _slab(self, rank):
+        L, ctx = self._lib, self._ctx
+        _capi.check(L, L.psim_stage_slab_positions(ctx, *self.band_of(rank)))
+
+    def _timed(self, name):
+        sps = self
+
+        class _T:
+            def __enter__(self):
+                sps._sync()
+                self.t0 = time.perf_counter()
+
+            def __exit__(self, *a):
+                sps._sync()
+                sps.emulated_ms[name] = sps.emulated_ms.get(name, 0.0) + (time.perf_counter() - self.t0) * 1e3
+        return _T() if self._emulate is not None else contextlib.nullcontext()
 
     def update(self, steps: int = 1):
         L, ctx = self._lib, self._ctx
+        W, me = self._world, self._rank
+        emu = self._emulate is not None
+        acc_ptr = ctypes.c_void_p(self._acc.data_ptr())
         for _ in range(int(steps)):
             self._sync_config()
             self._sync_state()
-            _capi.check(L, L.psim_stage_build(ctx))
+            with self._timed("build"):
+                _capi.check(L, L.psim_stage_build(ctx))
             n = int(L.psim_num_particles(ctx))
-            lo, hi, per = shard_range(n, self._rank, self._world)
-            # The walk is only submitted here (to the device's default stream, which is
-            # also PyTorch's); the exchange is started behind it, and while both are in
-            # flight the half of the contact solver that needs no velocities runs on the
-            # library's second stream.
-            _capi.check(L, L.psim_stage_gravity(ctx, lo, hi, ctypes.c_void_p(self._acc.data_ptr())))
-            detected = None
-            if (self._stage_mask & _capi.STAGE_COLLISIONS) and n > 0:
-                detected = self._detect_and_gather(lo, hi)
-            work = self._gather(self._acc, per, async_op=True)
-            if detected is not None:
-                keys, n_keys, cand, coinc = detected
-                _capi.check(L, L.psim_stage_settle_positions_from(ctx, ctypes.c_void_p(keys.data_ptr()), n_keys,
-                                                                  cand, coinc))
-            else:
-                _capi.check(L, L.psim_stage_settle_positions(ctx))
-            # (the library's main stream is the device's default stream, which is also the
-            # stream work.wait() makes wait for the collective: no host synchronisation)
-            if work is not None:
-                work.wait()
-            _capi.check(L, L.psim_stage_kick_collide(ctx, ctypes.c_void_p(self._acc.data_ptr())))
-            _capi.check(L, L.psim_stage_conduction(ctx, lo, hi, ctypes.c_void_p(self._tmp.data_ptr())))
-            exchanges = ctypes.c_int32(0)
-            _capi.check(L, L.psim_stage_conduction_exchanges(ctx, ctypes.byref(exchanges)))
-            if exchanges.value:      # same answer on every rank
-                self._gather(self._tmp, per)
-            _capi.check(L, L.psim_stage_finish(ctx, ctypes.c_void_p(self._tmp.data_ptr())))
+            lo, hi, per = shard_range(n, me, W)
+            # The walk is only submitted here (to the device's default stream, which is also
+            # PyTorch's); the exchange of accelerations is started behind it, and while both are
+            # in flight the position half of this rank's slab runs on the library's second stream.
+            with self._timed("walk_and_slab_positions"):
+                _capi.check(L, L.psim_stage_gravity(ctx, lo, hi, acc_ptr))
+                work = self._gather_acc_start(per) if self._transport == "device" else None
+                self._slab(me)
+                if self._transport != "device":
+                    self._gather_acc_start(per)
+                if work is not None:
+                    work.wait()      # (makes the default stream, the library's main stream, wait: no host synchronisation)
+            if emu:
+                for k in range(W):
+                    if k != me:
+                        klo, khi, _ = shard_range(n, k, W)
+                        _capi.check(L, L.psim_stage_gravity(ctx, klo, khi, acc_ptr))
+                self._sync()
+            with self._timed("kick_velocities_export"):
+                _capi.check(L, L.psim_stage_kick(ctx, acc_ptr))
+                _capi.check(L, L.psim_stage_slab_finish(ctx))
+                need = self._export(me)
+            self.exchange_bytes = {"accelerations_per_rank": 16 * per, "block_needed_this_rank": 8 * need,
+                                   "block_sent_per_rank": 8 * self._block_words}
+            while True:
+                if emu:
+                    # the other ranks' slabs, one after the other (the state arrays are untouched until the apply)
+                    needs = {me: need}
+                    for k in range(W):
+                        if k != me:
+                            self._slab(k)
+                            _capi.check(L, L.psim_stage_slab_finish(ctx))
+                            needs[k] = self._export(k)
+                            if needs[k] > self._block_words:
+                                break
+                    if max(needs.values()) > self._block_words:
+                        # a block did not fit: every block again with room (emulation only: the
+                        # real ranks keep their band's results and only export again)
+                        self._alloc_blocks(max(needs.values()) * 5 // 4 + 4096)
+                        self._slab(me)
+                        _capi.check(L, L.psim_stage_slab_finish(ctx))
+                        need = self._export(me)
+                        continue
+                else:
+                    self._gather_blocks()
+                status = ctypes.c_int32(0)
+                most = ctypes.c_int64(0)
+                with self._timed("apply"):
+                    _capi.check(L, L.psim_stage_apply(ctx, ctypes.c_void_p(self._blocks.data_ptr()), W, self._block_words,
+                                                      ctypes.byref(status), self._own_slots, ctypes.byref(most)))
+                if status.value != 2:
+                    break
+                # some rank's block did not fit: all ranks grow alike and export again
+                self._alloc_blocks(int(most.value) * 5 // 4 + 4096)
+                need = self._export(me)
+            with self._timed("finish"):
+                if status.value == 1:
+                    self.fallbacks += 1
+                    _capi.check(L, L.psim_stage_fallback(ctx))
+                _capi.check(L, L.psim_stage_finish(ctx))
+            self._rebalance()
             self._stale = True
             t = (ctypes.c_double * 3)()
             _capi.check(L, L.psim_collision_stats(ctx, t))

@@ -41,25 +41,42 @@ def main():
         kw["state"] = state
     else:
         g = load_golden(name)
+    # the unsharded run first, its states kept on the host, and its context closed: the sharded
+    # run that follows is then the only user of the device in this process
     ref = ParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds, **kw)
-    sh = ShardedParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds, **kw)
     v = g.init_velocities()
-    for s in (ref, sh):
-        if v is not None:
-            s.velocities = v
-        s._calculate_gravity()
+    if v is not None:
+        ref.velocities = v
+    ref._calculate_gravity()
+    want = []
     for step in range(1, steps + 1):
         ref.update()
+        want.append(dict(n=ref.num_particles, counts=ref.counts(),
+                         totals=(ref.pe_gain_collisions, ref.ke_loss_collisions, ref.heat_generated_collisions),
+                         **{f: getattr(ref, f).copy() for f in ("positions", "velocities", "accelerations", "temperatures")}))
+    ref.close()
+    sh = ShardedParticleSystem(g.n, dict(g.sim), g.rng(), g.bounds, **kw)
+    if v is not None:
+        sh.velocities = v
+    sh._calculate_gravity()
+    for step in range(1, steps + 1):
         if step == 2:
-            # a key buffer too small for this rank's contacts: psim_stage_detect must report the
-            # count, write nothing, and succeed when called again with room
-            sh._keys = sh._keys[:4].clone()        # (three counters + room for one key)
+            # blocks with room for the header only: psim_stage_slab_export must report what it
+            # needs and write nothing else, psim_stage_apply must say so on every rank, and the
+            # step must succeed once all ranks have made room
+            sh._alloc_blocks(32)
         sh.update()
-        assert ref.num_particles == sh.num_particles, (step, rank)
+        w = want[step - 1]
+        assert w["n"] == sh.num_particles, (step, rank)
         for f in ("positions", "velocities", "accelerations", "temperatures"):
-            a, b = getattr(ref, f), getattr(sh, f)
+            a, b = w[f], getattr(sh, f)
             assert np.array_equal(a, b), (step, rank, f, float(np.abs(a - b).max()))
-        assert ref.counts() == sh.counts(), (step, rank)
+        ca, cb = w["counts"], sh.counts()
+        for k in ("particles", "tree_nodes", "candidates", "contacts", "exploded", "internal_nodes"):
+            assert ca[k] == cb[k], (step, rank, k, ca, cb)
+        # (the three totals are sums of the ranks' partial sums: the same terms in another order)
+        u = (sh.pe_gain_collisions, sh.ke_loss_collisions, sh.heat_generated_collisions)
+        assert np.allclose(w["totals"], u, rtol=1e-11, atol=1e-300), (step, rank, w["totals"], u)
     # the shards tile the index space exactly
     n = 1000003
     cover = [shard_range(n, r, world) for r in range(world)]
@@ -67,7 +84,7 @@ def main():
     assert all(cover[i][1] == cover[i + 1][0] for i in range(world - 1))
     dist.barrier()
     dist.destroy_process_group()
-    print("rank %d ok: %s, %d steps, n %d -> %d" % (rank, name, steps, g.n, sh.num_particles))
+    print("rank %d ok: %s, %d steps, n %d -> %d, fallbacks %d" % (rank, name, steps, g.n, sh.num_particles, sh.fallbacks))
 
 
 if __name__ == "__main__":

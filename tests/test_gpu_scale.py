@@ -55,9 +55,9 @@ def test_c3_16Mi_rotating_disk_staged_vs_oracle(one_rank_rccl):
                               system_class=ShardedParticleSystem, min_contacts=100000)
 
 
-def test_staged_step_with_more_contacts_than_the_key_buffer(one_rank_rccl):
-    """a first step whose contacts exceed the sharded class's initial key buffer
-    (max(4096, n/8) keys): the buffer is regrown while the walk is in flight; the contact
+def test_staged_step_with_more_results_than_the_export_block(one_rank_rccl):
+    """a first step whose touched particles exceed the sharded class's initial export block:
+    the export reports what it needs, the block is regrown and exported again; the contact
     list must equal the unsharded step's"""
     from psim_amd.distributed import ShardedParticleSystem
     n = 60000
@@ -65,11 +65,11 @@ def test_staged_step_with_more_contacts_than_the_key_buffer(one_rank_rccl):
     state = dict(state, positions=np.array(bounds) / 2 + (state["positions"] - np.array(bounds) / 2) * 0.6)   # denser still
     a = ParticleSystem(n, dict(SIM), None, bounds, state=state, debug=True)
     b = ShardedParticleSystem(n, dict(SIM), None, bounds, state=state, debug=True)
-    assert b._keys.numel() < 20000
+    before = b._block_words
     for s in (a, b):
         s._calculate_gravity()
         s.update()
-    assert a.counts()["contacts"] > 20000
+    assert a.counts()["contacts"] > 20000 and b._block_words > before
     np.testing.assert_array_equal(a.debug_array("contact_ij"), b.debug_array("contact_ij"))
     for name in ("positions", "velocities", "temperatures"):
         np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)

@@ -72,38 +72,49 @@ def test_bad_arguments_are_value_errors():
 
 
 def test_staged_entry_points_reject_bad_ranges_and_work_by_hand():
-    """the multi-GPU stage calls driven directly through the C ABI on one rank: bad ranges are
-    PSIM_ERR_INVALID, a key buffer that is too small reports the count and writes nothing, and
-    detection split over two slabs hands the solver the same contacts as one sweep"""
+    """the multi-GPU stage calls driven directly through the C ABI, two bands solved one after
+    the other by hand: bad ranges are PSIM_ERR_INVALID, a block that is too small reports what
+    it needs and is marked incomplete, calls out of order are errors, and the two bands'
+    blocks applied together give the unsharded step"""
     n, bounds = 600, (420, 300)
     ref = ParticleSystem(n, dict(SIM), np.random.default_rng(4), bounds, library=HOSTLOOP, walk_mode=1, debug=True)
     s = ParticleSystem(n, dict(SIM), np.random.default_rng(4), bounds, library=HOSTLOOP, walk_mode=1, debug=True)
     ref._calculate_gravity(); s._calculate_gravity()
     ref.update()
     L, ctx = s._lib, s._ctx
+    gh = s.grid_height
+    assert gh == 4
     acc = np.zeros((n, 2))
-    tmp = np.zeros(n)
     vp = lambda a: ctypes.c_void_p(a.ctypes.data)
-    out = (ctypes.c_int64 * 4)()
+    assert L.psim_stage_kick(ctx, vp(acc)) == -2                       # not inside a staged step
     assert L.psim_stage_build(ctx) == 0
     assert L.psim_stage_gravity(ctx, 5, 3, vp(acc)) == -1              # lo > hi
     assert L.psim_stage_gravity(ctx, 0, n, vp(acc)) == 0
-    keys = np.zeros(4096, dtype=np.uint64)
-    assert L.psim_stage_detect(ctx, 2, n, vp(keys), 4096, out) == -1   # lo not a multiple of 4
-    assert L.psim_stage_detect(ctx, 0, n + 1, vp(keys), 4096, out) == -1
-    assert L.psim_stage_detect(ctx, 0, 256, vp(keys), 0, out) == 0
-    first, cand_a, coin_a = out[0], out[1], out[2]
-    assert first > 0 and out[3] == 0                                   # no room: counted, nothing written
-    assert L.psim_stage_detect(ctx, 0, 256, vp(keys), 4096, out) == 0 and out[3] == first
-    rest = np.zeros(4096, dtype=np.uint64)
-    assert L.psim_stage_detect(ctx, 256, n, vp(rest), 4096, out) == 0
-    allk = np.concatenate([rest[: out[0]], keys[:first]])              # any order
-    assert L.psim_stage_settle_positions_from(ctx, vp(allk), len(allk), cand_a + out[1], coin_a + out[2]) == 0
-    assert L.psim_stage_kick_collide(ctx, vp(acc)) == 0
-    assert L.psim_stage_conduction(ctx, 0, n, vp(tmp)) == 0
-    assert L.psim_stage_finish(ctx, vp(tmp)) == 0
+    assert L.psim_stage_slab_positions(ctx, 0, gh + 1, 0, 2) == -1     # rows beyond the grid
+    assert L.psim_stage_slab_positions(ctx, 1, gh, 0, 2) == -1         # own rows outside the band
+    assert L.psim_stage_finish(ctx) == -2                              # nothing applied yet
+    assert L.psim_stage_kick(ctx, vp(acc)) == 0
+    words = 1 << 16
+    blocks = np.zeros(2 * words, dtype=np.uint64)
+    need = ctypes.c_int64(0)
+    for r, (own_lo, own_hi) in enumerate([(0, 2), (2, gh)]):
+        assert L.psim_stage_slab_positions(ctx, 0, gh, own_lo, own_hi) == 0     # (two halo rows cover this small grid)
+        assert L.psim_stage_slab_finish(ctx) == 0
+        block = blocks[r * words:(r + 1) * words]
+        assert L.psim_stage_slab_export(ctx, vp(block), 8, ctypes.byref(need)) == -1      # smaller than a header
+        assert L.psim_stage_slab_export(ctx, vp(block), 32, ctypes.byref(need)) == 0
+        assert need.value > 32 and block[15] == 0 and block[11] == need.value             # incomplete: header only
+        assert L.psim_stage_slab_export(ctx, vp(block), words, ctypes.byref(need)) == 0
+        assert block[15] == 1 and block[0] > 0                                           # touched particles of the own rows
+    status = ctypes.c_int32(-1)
+    own = (ctypes.c_int64 * 2)()
+    assert L.psim_stage_apply(ctx, vp(blocks), 2, words, ctypes.byref(status), own, ctypes.byref(need)) == 0
+    assert status.value == 0 and own[0] + own[1] == n
+    assert L.psim_stage_finish(ctx) == 0
     s._stale = True
-    assert s.counts() == ref.counts()
+    cs, cr = s.counts(), ref.counts()
+    for k in ("particles", "tree_nodes", "candidates", "contacts", "exploded"):
+        assert cs[k] == cr[k], k
     for name in ("positions", "velocities", "temperatures"):
         np.testing.assert_array_equal(getattr(s, name), getattr(ref, name), err_msg=name)
     ms = ctypes.c_double(0.0)
