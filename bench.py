@@ -122,13 +122,23 @@ def launch_ranks(n_ranks):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # all children are watched together: when one fails the others (blocked in the next
+    # collective) are ended and its exit code is reported at once
     rc = 0
+    deadline = time.time() + float(os.environ.get("PSIM_BENCH_RANKS_TIMEOUT", "3000"))
     try:
-        for p in procs:
-            code = p.wait()
-            rc = rc or code
-            if code != 0:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
                 break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                rc = 124
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -243,17 +253,28 @@ def main():
             torch.cuda.synchronize()
 
     stage_acc = {}
+    steps = max(args.steps, 1)
     barrier()
     t0 = time.perf_counter()
     updates = 0
-    for _ in range(args.steps):
-        ps.update()
-        updates += ps.num_particles
-        for k, v in ps.stage_times_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
-    barrier()
-    dt = time.perf_counter() - t0
-    steps = max(args.steps, 1)
+    if world == 1 and not args.staged:
+        # all K steps in one call of the library: nothing between two steps but the next
+        # step's launches; the stage times are averages the library takes from HIP events it
+        # recorded along the way, read after the call
+        ps.update(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        updates = ps.particle_updates()
+        stage_ms = ps.stage_times_ms()
+    else:
+        for _ in range(args.steps):
+            ps.update()
+            updates += ps.num_particles
+            for k, v in ps.stage_times_ms().items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
+        barrier()
+        dt = time.perf_counter() - t0
+        stage_ms = {k: v / steps for k, v in stage_acc.items()}
     emulated = None
     if emulate is not None:
         # the rank's own share: the sum of its timed pieces (host clock, device idle at both
@@ -272,7 +293,6 @@ def main():
                                                  "assumed_GB_per_s_per_link": link_gbs},
                     "rows": ps._row_bounds, "fallbacks": ps.fallbacks,
                     "note": "ms_per_step and value are this rank's compute share only (exchanges excluded)"}
-    stage_ms = {k: v / steps for k, v in stage_acc.items()}
     walk_ms_ranks = [stage_ms.get("gravity", 0.0)]
     if world > 1:
         # one simulation: every rank counted the same updates; time = slowest rank

@@ -63,7 +63,10 @@ typedef struct psim_config {
                                          compiler's instruction schedule of the walk loop instead of the
                                          hand-written one (tests: both must agree bit for bit) */
     int32_t debug;                    /* bit 0: keep the per-step contact log and delta-temperature array;
-                                         bit 1: take the contact solver's large-hypothesis path at any size (tests) */
+                                         bit 1: take the contact solver's large-hypothesis path at any size (tests);
+                                         bit 2: the contact solver's re-test trusts no per-slot digest and looks at
+                                         every candidate pair around every touched slot in every iteration (tests:
+                                         the contact lists must be the same with and without) */
     int32_t overlap;                  /* 1 = run the grid build and the first contact-sweep count pass on a
                                          side stream underneath the tree walk (default in the Python binding) */
 } psim_config;
@@ -97,6 +100,10 @@ int psim_prime_gravity(psim_context* ctx);
 
 /* replaces: ParticleSystem.update() called k_steps times (particle_system.py:518-563) */
 int psim_step(psim_context* ctx, int64_t k_steps);
+
+/* particles alive after each step, summed over the steps of the last psim_step call (the
+ * number of particle-updates it performed; explosions shrink the count, particle_system.py:725) */
+int64_t psim_particle_updates(psim_context* ctx);
 
 /* One simulation split over several GPUs (no counterpart in the reference, which is
  * single-process): psim_step cut at its exchange points.  Every rank holds the full state
@@ -212,13 +219,15 @@ int psim_render_feed(psim_context* ctx, int32_t* xy_out, uint8_t* rgba_out);
 int psim_pair_potential_energy(psim_context* ctx, double* out);
 
 /* No counterpart in the reference.  psim_pair_potential_energy for callers that cannot
- * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc): same kernels, same result bit for bit, but every intermediate (one row
- * sum per particle, the reduction's partial sums) lives in a fixed device array inside the
- * library (2 MiB + 8 KiB per GPU, held until the process ends) and the call makes no
- * hipMalloc / hipFree or other allocating call.  At most 262,144 particles: more is
- * PSIM_ERR_INVALID with a message naming the limit.  All contexts on one GPU share that
- * array: calls that overlap in time on the same GPU race (calls on different GPUs do not). */
+ * allocate device memory (tight serving loops, harnesses that forbid hipMalloc): same
+ * kernels, same result bit for bit, but every intermediate (one row sum per particle, the
+ * reduction's partial sums) lives in a fixed device array inside the library (2 MiB + 8 KiB
+ * per GPU, held until the process ends) and the call makes no hipMalloc / hipFree or other
+ * allocating call.  It is synchronous like every other entry point (the result is read back
+ * from the context's stream, the device's default stream), so it cannot itself run under a
+ * HIP graph capture.  At most 262,144 particles: more is PSIM_ERR_INVALID with a message
+ * naming the limit.  All contexts on one GPU share that array: calls that overlap in time on
+ * the same GPU race (calls on different GPUs do not). */
 int psim_pair_potential_energy_noalloc(psim_context* ctx, double* out);
 
 /* parity hooks: copy a named internal device array to the host.
@@ -234,7 +243,8 @@ int psim_debug_fetch(psim_context* ctx, const char* name, void* dst, size_t byte
 int psim_selftest(int device_ordinal, int64_t n, uint64_t seed);
 
 /* timing hook for benchmarks: device-side duration in milliseconds of each
- * stage of the LAST psim_step call (HIP events on the context's stream):
+ * stage, averaged over the steps of the LAST psim_step call (its first 64 steps; HIP events
+ * on the context's stream, read after the call: no synchronisation inside it):
  * [0] drift+keys, [1] grid build, [2] tree build, [3] gravity walk, [4] kick,
  * [5] collisions, [6] conduction+cooling, [7] walls+explosions */
 int psim_stage_times(psim_context* ctx, double out_ms[8]);

@@ -2,6 +2,7 @@
 // bodies, and the cooperative primitives the step needs -- LDS-staged LSD radix
 // sort, exclusive scan, ordered f64 reduction.  64-lane wavefronts throughout.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <string.h>
@@ -1417,37 +1418,69 @@ namespace psim {
 namespace be {
 struct StageTimer {
     static constexpr int kMarks = 9;
-    hipEvent_t ev[kMarks];
-    int src[kMarks] = {0, 1, 2, 3, 4, 5, 6, 7, 8};     // mark i was taken at event src[i]
-    bool ready = false, complete = false;
-    void init()
-    {
-        if (ready) return;
-        for (int i = 0; i < kMarks; ++i) PSIM_HIP(hipEventCreate(&ev[i]));
-        ready = true;
-    }
+    static constexpr int kMaxSets = 64;
+    // One set of events per step of the current psim_step call (the first kMaxSets steps of
+    // it; later steps reuse the last set), so that a call of many steps is timed without a
+    // host synchronisation per step: read() averages over the sets after the call's end.
+    struct Set {
+        hipEvent_t ev[kMarks];
+        int src[kMarks];           // mark i was taken at event src[i]
+        bool complete;
+    };
+    std::vector<Set> sets;
+    int cur = -1, used = 0;
+    void init() { if (cur < 0) next_step(); }
     void destroy()
     {
-        if (!ready) return;
-        for (int i = 0; i < kMarks; ++i) (void)hipEventDestroy(ev[i]);
-        ready = false;
+        for (Set& s : sets)
+            for (int i = 0; i < kMarks; ++i) (void)hipEventDestroy(s.ev[i]);
+        sets.clear();
+        cur = -1; used = 0;
     }
-    void mark(Stream st, int i) { init(); PSIM_HIP(hipEventRecord(ev[i], st)); src[i] = i; if (i == kMarks - 1) complete = true; }
+    void begin_call() { used = 0; cur = -1; }
+    void next_step()
+    {
+        if (used < kMaxSets) {
+            if (used == (int)sets.size()) {
+                Set s;
+                for (int i = 0; i < kMarks; ++i) PSIM_HIP(hipEventCreate(&s.ev[i]));
+                sets.push_back(s);
+            }
+            cur = used++;
+        }
+        Set& s = sets[cur];
+        for (int i = 0; i < kMarks; ++i) s.src[i] = i;
+        s.complete = false;
+    }
+    void mark(Stream st, int i)
+    {
+        init();
+        Set& s = sets[cur];
+        PSIM_HIP(hipEventRecord(s.ev[i], st));
+        s.src[i] = i;
+        if (i == kMarks - 1) s.complete = true;
+    }
     // mark j at the place of mark i (nothing was submitted in between): no second record
-    void same_as(int j, int i) { src[j] = src[i]; }
+    void same_as(int j, int i) { init(); sets[cur].src[j] = sets[cur].src[i]; }
     // a mark doubles as the event other streams or the host wait on (every record costs the
     // stream some 6 us, so the step does not record a second event where a mark already is)
-    Event event(int i) { init(); return ev[i]; }
+    Event event(int i) { init(); return sets[cur].ev[i]; }
     void read(double* ms)
     {
         for (int i = 0; i < kMarks - 1; ++i) ms[i] = 0.0;
-        if (!complete) return;
-        PSIM_HIP(hipEventSynchronize(ev[kMarks - 1]));
-        for (int i = 0; i < kMarks - 1; ++i) {
-            float t = 0.f;
-            if (src[i] != src[i + 1]) PSIM_HIP(hipEventElapsedTime(&t, ev[src[i]], ev[src[i + 1]]));
-            ms[i] = (double)t;
+        int counted = 0;
+        for (int k = 0; k < used; ++k) {
+            Set& s = sets[k];
+            if (!s.complete) continue;
+            PSIM_HIP(hipEventSynchronize(s.ev[kMarks - 1]));
+            for (int i = 0; i < kMarks - 1; ++i) {
+                float t = 0.f;
+                if (s.src[i] != s.src[i + 1]) PSIM_HIP(hipEventElapsedTime(&t, s.ev[s.src[i]], s.ev[s.src[i + 1]]));
+                ms[i] += (double)t;
+            }
+            ++counted;
         }
+        if (counted > 1) for (int i = 0; i < kMarks - 1; ++i) ms[i] /= counted;
     }
 };
 }  // namespace be

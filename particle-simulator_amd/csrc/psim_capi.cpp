@@ -201,6 +201,8 @@ int psim_download(psim_context* ctx, double* positions, double* velocities, doub
 
 int64_t psim_num_particles(psim_context* ctx) { return ctx ? ctx->sim->n : -1; }
 
+int64_t psim_particle_updates(psim_context* ctx) { return ctx ? ctx->sim->updates_in_call : -1; }
+
 int psim_prime_gravity(psim_context* ctx)
 {
     PSIM_TRY(ctx, {
@@ -213,6 +215,8 @@ int psim_step(psim_context* ctx, int64_t k_steps)
 {
     PSIM_TRY(ctx && k_steps >= 0, {
         use_device(ctx->device);
+        ctx->sim->timer.begin_call();
+        ctx->sim->updates_in_call = 0;
         for (int64_t k = 0; k < k_steps; ++k) ctx->sim->step();
         psim::be::sync(ctx->sim->st);
     })
@@ -222,6 +226,7 @@ int psim_stage_build(psim_context* ctx)
 {
     PSIM_TRY(ctx, {
         use_device(ctx->device);
+        ctx->sim->timer.begin_call();
         ctx->sim->stage_build();
         psim::be::sync(ctx->sim->st);
     })
@@ -585,9 +590,10 @@ static bool find_debug_array(psim::Sim* s, const std::string& name, DebugArray* 
     else if (name == "node_last") *a = {s->node_last.p, s->n_internal, 4};
     else if (name == "node_depth") *a = {s->node_depth[0].p, s->n_internal, 4};
     else if (name == "depth_offsets") *a = {s->depth_off.p, psim::kKeyLevels + 2, 4};
-    else if (name == "grid_offsets") *a = {s->offsets.p, cells + 1, 4};
-    else if (name == "grid_indices") *a = {s->cperm[s->sorted_ckey].p, n, 4};
-    else if (name == "cell_key") *a = {s->ckey[s->sorted_ckey].p, n, 4};
+    // (the grid arrays exist when the last step built the whole grid: a step split by bands of rows may not)
+    else if (name == "grid_offsets") *a = {s->offsets.p, s->full_grid_valid ? cells + 1 : 0, 4};
+    else if (name == "grid_indices") *a = {s->cperm[s->sorted_ckey].p, s->full_grid_valid ? n : 0, 4};
+    else if (name == "cell_key") *a = {s->ckey[s->sorted_ckey].p, s->full_grid_valid ? n : 0, 4};
     else if (name == "contact_ij") *a = {s->log_ij.p, s->log_n, 8};
     else if (name == "contact_vals") *a = {s->log_vals.p, s->log_n, 24};
     else if (name == "delta_temps") *a = {s->delta_dbg.p, s->delta_dbg.p ? n : 0, 8};

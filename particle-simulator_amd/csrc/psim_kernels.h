@@ -1432,6 +1432,10 @@ struct SegDisplacement {
     const uint64_t* sig;
     uint64_t* dsig;            // [first adjacency entry of the slot] this iteration's digest (EndIteration moves it to sig)
     uint8_t* changed;
+    // 1: every touched slot counts as changed in every iteration, i.e. the re-test trusts no
+    // digest and looks at every candidate pair around every touched slot again (the check
+    // that the digests' shortcut never alters a contact list)
+    int32_t all_changed;
     static PSIM_HD PSIM_FORCEINLINE uint64_t mix(uint64_t h)
     {
         h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
@@ -1462,7 +1466,7 @@ struct SegDisplacement {
         double bound = sqrt(m) * (1.0 + 1e-6) + 1e-9;
         dseg[e] = bound;
         raise_to_u32(dmax_bits, float_bits_at_least(bound));
-        changed[x] = sig[x] != digest ? 1 : 0;
+        changed[x] = (all_changed || sig[x] != digest) ? 1 : 0;
         dsig[e] = digest;
     }
 };

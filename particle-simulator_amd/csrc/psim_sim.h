@@ -687,7 +687,7 @@ public:
             sperm = perm[sorted_key].p;
             be::launch(st, n, GatherTree{n, sperm, pack.p, spos.p, smass.p});
             hilbert_ready = false;
-            if (walk_uses_order()) {
+            {
                 // cells along the curve, each cell's particles in Morton order: no sort needed
                 // (three streaming passes and a scan over the cells; they look at the word
                 // FixRuns raises and do nothing when the keys are still to be sorted again)
@@ -769,7 +769,6 @@ public:
     // the walks take their targets in Hilbert order (every walk kernel accepts it; the
     // one-lane-per-particle walk gains nothing from it and is given it all the same, so that
     // the test-only host-loop build, which has no other walk, covers the ordering kernels)
-    bool walk_uses_order() const { return true; }
     const uint32_t* walk_order() const { return hilbert_ready ? hord.p : nullptr; }
     // curve_pos[c]: where the quadtree cell with Morton path c (depth `levels`) comes when the
     // cells are put in the order of their centres along a fine Hilbert curve over the square
@@ -1030,7 +1029,7 @@ public:
                 dseg.ensure(2 * (size_t)nH); dsig.ensure(2 * (size_t)nH);
                 auto displacement_and_changes = [&]() {
                     be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1,
-                                                               H, slot_sig.p, dsig.p, slot_changed.p});
+                                                               H, slot_sig.p, dsig.p, slot_changed.p, (cfg.debug & 4) ? 1 : 0});
                     if (cap_prev > 0)
                         be::launch(ln.s, cap_prev, MarkUntouched{cap_prev, prev_slots[prev_list].p, ctr + 9 + prev_list, cseg.p,
                                                                  slot_sig.p, slot_changed.p});
@@ -1507,8 +1506,10 @@ public:
         side_running = false;
         refresh_groups();
     }
+    int64_t updates_in_call = 0;       // particles alive after each step, summed over the steps of the last psim_step call
     void begin_step()
     {
+        timer.next_step();
         n_exploded = 0;
         last_exploded.clear();
         moved_valid = false;
@@ -1563,6 +1564,7 @@ public:
         uint32_t nb = walls_and_flags(sparse);
         if (nb > 0) explosions(nb);
         timer.mark(st, 8);
+        updates_in_call += n;
     }
 
     // ---- The same step cut at its exchange points, for one simulation split over several

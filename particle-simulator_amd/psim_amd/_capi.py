@@ -20,7 +20,7 @@ STAGE_ALL = 31
 
 EXPORTS = [
     "psim_create", "psim_destroy", "psim_set_config", "psim_upload", "psim_download",
-    "psim_num_particles", "psim_prime_gravity", "psim_step", "psim_energies",
+    "psim_num_particles", "psim_particle_updates", "psim_prime_gravity", "psim_step", "psim_energies",
     "psim_collision_stats", "psim_counts", "psim_explosion_events", "psim_walk_counts",
     "psim_debug_size", "psim_debug_fetch", "psim_selftest", "psim_stage_times",
     "psim_last_error", "psim_version",
@@ -73,7 +73,10 @@ def load(path=None):
         # first makes the process use ONE runtime -- PyTorch's -- for both: memory pinned by
         # PyTorch is then pinned for this library's copies too.  (The other order leaves
         # PyTorch unable to see the GPU.)
-        import torch  # noqa: F401
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass      # (no PyTorch: the public arrays are then ordinary, unpinned NumPy blocks)
     try:
         L = ctypes.CDLL(path)
     except OSError as e:
@@ -88,6 +91,8 @@ def load(path=None):
     L.psim_download.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.psim_num_particles.argtypes = [vp]
     L.psim_num_particles.restype = ctypes.c_int64
+    L.psim_particle_updates.argtypes = [vp]
+    L.psim_particle_updates.restype = ctypes.c_int64
     L.psim_prime_gravity.argtypes = [vp]
     L.psim_step.argtypes = [vp, ctypes.c_int64]
     L.psim_energies.argtypes = [vp, c_dp]

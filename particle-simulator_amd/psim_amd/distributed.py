@@ -305,6 +305,7 @@ class ShardedParticleSystem(ParticleSystem):
                 _capi.check(L, L.psim_stage_finish(ctx))
             self._rebalance()
             self._stale = True
+            self._stepped = True
             t = (ctypes.c_double * 3)()
             _capi.check(L, L.psim_collision_stats(ctx, t))
             self.pe_gain_collisions, self.ke_loss_collisions, self.heat_generated_collisions = t[0], t[1], t[2]

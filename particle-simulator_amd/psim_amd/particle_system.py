@@ -17,6 +17,7 @@ read-only, so an in-place edit (`ps.velocities[0] = ...`) raises instead of
 being lost; `with ps.editing() as arrays:` gives writable views and uploads
 them on exit.
 """
+import collections
 import ctypes
 import logging
 
@@ -26,6 +27,18 @@ from . import _capi
 from . import constants
 
 logger = logging.getLogger("particle_sim")
+
+# quadtree.py:11 (the root box the reference's constructor logs, particle_system.py:400,407)
+BoundingBox = collections.namedtuple('BoundingBox', ['x', 'y', 'width', 'height'])
+
+
+class _QuadTreeHandle:
+    """What `ParticleSystem.qtree` is here: the root box (quadtree.py:146); the tree itself
+    lives on the device (`ParticleSystem.canonical_tree()` reads it back)."""
+
+    def __init__(self, boundary):
+        self.boundary = boundary
+        self.capacity = 1
 
 
 def grid_geometry(config, bounds):
@@ -125,10 +138,14 @@ class ParticleSystem:
             np.copyto(self._host[name], value)
         self._stale = False
         self._dirty = False
+        self._stepped = False
         self._upload()
+        qtree_boundary = BoundingBox(x=0, y=0, width=self.bounds[0], height=self.bounds[1])
+        self.qtree = _QuadTreeHandle(qtree_boundary)
         logger.info(f"ParticleSystem created for {num_particles} particles.")
         logger.info(f"Spatial grid initialized with cell size {self.cell_size} "
                     f"({self.grid_width}x{self.grid_height} cells).")
+        logger.info(f"QuadTree initialized with boundary: {qtree_boundary}")
 
     # ------------------------------------------------------------------ plumbing
     def _config_key(self):
@@ -156,7 +173,13 @@ class ParticleSystem:
         owns the memory; the device copies into and out of it by DMA)."""
         if not self._pinned:
             return None, np.empty((rows, cols), dtype=dtype)
-        import torch
+        try:
+            import torch
+        except ImportError:
+            # (without PyTorch the blocks are ordinary memory: copies then go through the
+            # runtime's staging buffer, everything else is unchanged)
+            self._pinned = False
+            return None, np.empty((rows, cols), dtype=dtype)
         t = torch.empty((max(rows, 1), cols), dtype=getattr(torch, np.dtype(dtype).name), pin_memory=True)
         return t, t.numpy()[:rows]
 
@@ -221,6 +244,7 @@ class ParticleSystem:
         """Full state + configuration as one .npz: a run restored from it continues
         bit-identically (the step holds no other state between calls)."""
         import json
+        self._sync_state()
         self._refresh()
         h = self._host
         np.savez(path, positions=h["positions"], velocities=h["velocities"], accelerations=h["accelerations"],
@@ -268,6 +292,7 @@ class ParticleSystem:
         self._sync_state()
         _capi.check(self._lib, self._lib.psim_step(self._ctx, int(steps)))
         self._stale = True
+        self._stepped = True
         t = (ctypes.c_double * 3)()
         _capi.check(self._lib, self._lib.psim_collision_stats(self._ctx, t))
         self.pe_gain_collisions, self.ke_loss_collisions, self.heat_generated_collisions = t[0], t[1], t[2]
@@ -319,6 +344,7 @@ class ParticleSystem:
 
     # ------------------------------------------------------------------ diagnostics
     def counts(self):
+        self._sync_state()
         out = (ctypes.c_int64 * 8)()
         _capi.check(self._lib, self._lib.psim_counts(self._ctx, out))
         keys = ("particles", "tree_nodes", "candidates", "contacts", "exploded", "internal_nodes",
@@ -326,6 +352,7 @@ class ParticleSystem:
         return dict(zip(keys, out))
 
     def walk_counts(self):
+        self._sync_state()
         out = (ctypes.c_int64 * 4)()
         _capi.check(self._lib, self._lib.psim_walk_counts(self._ctx, out))
         self.last_walk_trips = (int(out[2]), int(out[3]))
@@ -334,6 +361,7 @@ class ParticleSystem:
     def time_walk(self, reps=3, slots_per_simd=0.0):
         """Average milliseconds of the default walk kernel on the current tree with the
         device to itself (0 = whole grid at once; else that many resident waves per SIMD)."""
+        self._sync_state()
         ms = ctypes.c_double(0.0)
         _capi.check(self._lib, self._lib.psim_time_walk(self._ctx, int(reps), float(slots_per_simd), ctypes.byref(ms)))
         return ms.value
@@ -369,6 +397,10 @@ class ParticleSystem:
         _capi.check(self._lib, self._lib.psim_pair_potential_energy(self._ctx, ctypes.byref(out)))
         return out.value
 
+    def particle_updates(self):
+        """particles alive after each step, summed over the steps of the last update() call"""
+        return int(self._lib.psim_particle_updates(self._ctx))
+
     def stage_times_ms(self):
         out = (ctypes.c_double * 8)()
         _capi.check(self._lib, self._lib.psim_stage_times(self._ctx, out))
@@ -385,7 +417,25 @@ class ParticleSystem:
         "delta_temps": (np.float64, ()), "exploded": (np.int32, ()), "tree_path": (np.uint32, ()),
     }
 
+    @property
+    def grid_offsets(self):
+        """particle_system.py:393 (read-only copy): CSR offsets of the last step's grid, zeros
+        before the first step as in the reference"""
+        cells = self.grid_width * self.grid_height
+        a = self.debug_array("grid_offsets") if self._stepped else np.zeros(cells + 1, dtype=np.int32)
+        a.flags.writeable = False
+        return a
+
+    @property
+    def grid_indices(self):
+        """particle_system.py:395 (read-only copy): particle indices sorted by cell, of the last
+        step's grid (it holds the particles the step started with)"""
+        a = self.debug_array("grid_indices") if self._stepped else np.zeros(self.num_particles, dtype=np.int32)
+        a.flags.writeable = False
+        return a
+
     def debug_array(self, name):
+        self._sync_state()
         dtype, tail = self._DEBUG_DTYPES[name]
         cnt = int(self._lib.psim_debug_size(self._ctx, name.encode()))
         if cnt < 0:

@@ -119,16 +119,25 @@ namespace be {
 struct StageTimer {
     static constexpr int kMarks = 9;
     std::chrono::steady_clock::time_point t[kMarks];
-    bool complete = false;
+    double sum[kMarks] = {0};
+    int steps = 0;
     void init() {}
     void destroy() {}
-    void mark(Stream, int i) { t[i] = std::chrono::steady_clock::now(); if (i == kMarks - 1) complete = true; }
+    void begin_call() { steps = 0; for (int i = 0; i < kMarks; ++i) sum[i] = 0.0; }
+    void next_step() {}
+    void mark(Stream, int i)
+    {
+        t[i] = std::chrono::steady_clock::now();
+        if (i == kMarks - 1) {
+            for (int k = 0; k < kMarks - 1; ++k) sum[k] += std::chrono::duration<double, std::milli>(t[k + 1] - t[k]).count();
+            ++steps;
+        }
+    }
     Event event(int) { return 0; }
     void same_as(int j, int i) { t[j] = t[i]; }
     void read(double* ms)
     {
-        for (int i = 0; i < kMarks - 1; ++i)
-            ms[i] = complete ? std::chrono::duration<double, std::milli>(t[i + 1] - t[i]).count() : 0.0;
+        for (int i = 0; i < kMarks - 1; ++i) ms[i] = steps ? sum[i] / steps : 0.0;
     }
 };
 }  // namespace be

@@ -31,7 +31,7 @@ def test_device_primitives(n):
 
 
 @pytest.mark.parametrize("walk_mode", [0, 1, 2])
-@pytest.mark.parametrize("name", ["tiny64", "dense256", "dense400", "hot300", "fast200"])
+@pytest.mark.parametrize("name", ["tiny64", "dense256", "dense400", "hot300", "fast200", "hotall60"])
 def test_golden_stepwise(name, walk_mode):
     parity.run_golden_stepwise(name, HIP, walk_mode=walk_mode)
 
@@ -99,6 +99,18 @@ def test_large_hypothesis_path_forced_vs_oracle():
     parity.run_against_oracle(30000, SIM, 1, bounds, 2, HIP, state=st, oracle_threads=_host_threads(), debug=3)
     sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)
     parity.run_against_oracle(20000, sim, 6, (3000, 1700), 3, HIP, debug=3)
+
+
+def test_full_retest_mode_of_the_contact_solver_vs_oracle():
+    """debug bit 2: the re-test trusts no per-slot digest (every touched slot counts as changed
+    in every iteration, nothing is carried over unexamined).  The contact lists of the dense
+    cases must equal the oracle's exactly as they do with the digests' shortcut, i.e. the
+    shortcut changed none of them"""
+    bounds = (4000, 4000)
+    st = parity.gaussian_cluster_state(30000, bounds, 250.0, 3)
+    parity.run_against_oracle(30000, SIM, 1, bounds, 2, HIP, state=st, oracle_threads=_host_threads(), debug=5)
+    sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)
+    parity.run_against_oracle(20000, sim, 6, (3000, 1700), 3, HIP, debug=5)
 
 
 def test_oracle_dense_hot_20k():

@@ -143,6 +143,19 @@ def test_large_hypothesis_path_of_the_contact_solver_vs_oracle():
     parity.run_against_oracle(2500, sim, 6, (1060, 600), 3, HOSTLOOP, walk_mode=1, debug=3)
 
 
+def test_full_retest_mode_of_the_contact_solver_vs_oracle():
+    """debug bit 2: the re-test trusts no per-slot digest (every touched slot counts as changed
+    in every iteration, nothing is carried over unexamined).  The contact lists of the dense
+    cases must equal the oracle's exactly as they do with the digests' shortcut, i.e. the
+    shortcut changed none of them (small and large-hypothesis paths)"""
+    n, bounds = 6000, (900, 900)
+    st = parity.gaussian_cluster_state(n, bounds, 90.0, 3)
+    parity.run_against_oracle(n, SIM, 1, bounds, 3, HOSTLOOP, walk_mode=1, state=st, debug=5, min_contacts=3000)
+    parity.run_against_oracle(n, SIM, 1, bounds, 2, HOSTLOOP, walk_mode=1, state=st, debug=7, min_contacts=2000)
+    sim = dict(SIM, min_temp=0.8, max_temp=1.02, collision_solver_iterations=2)
+    parity.run_against_oracle(2500, sim, 6, (1060, 600), 3, HOSTLOOP, walk_mode=1, debug=5)
+
+
 def test_tree_walk_against_all_pairs():
     """theta = 0 opens every node, so the walk must reproduce the all-pairs sum (to
     summation order); theta = 0.5 must stay within Barnes-Hut's approximation error"""

@@ -26,9 +26,25 @@ def both(ps):
     return a.value, b.value
 
 
+def free_device_memory():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info(0)[0]
+
+
 def test_no_alloc_entry_point_matches_on_two_calls_in_a_row():
     big = ParticleSystem(50000, dict(SIM), np.random.default_rng(1), (7000, 7000))
     small = ParticleSystem(3001, dict(SIM), np.random.default_rng(2), (1700, 1700))
+    # the property that defines the entry point: the device's free memory is the same before
+    # and after, from a fresh context's very first call on (the scratch array's address was
+    # resolved when the context was created)
+    fresh = ParticleSystem(40000, dict(SIM), np.random.default_rng(9), (6000, 6000))
+    out = ctypes.c_double(0.0)
+    before = free_device_memory()
+    for ps in (fresh, fresh, small):
+        _capi.check(ps._lib, ps._lib.psim_pair_potential_energy_noalloc(ps._ctx, ctypes.byref(out)))
+        assert free_device_memory() == before
+    fresh.close()
     a, b = both(big)
     assert a == b and a < 0.0                      # bit-identical (same kernels, same association)
     a2, b2 = both(small)                           # smaller input on the scratch the first call left
