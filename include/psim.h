@@ -193,6 +193,14 @@ int64_t psim_explosion_events(psim_context* ctx, psim_explosion_event* buf, int6
  * summed over 64-lane waves, [3] trips in which some lane accepted */
 int psim_walk_counts(psim_context* ctx, int64_t out[4]);
 
+/* the same counted walk with the lane statistics of its loop (no counterpart in the reference):
+ * [0..3] as psim_walk_counts; of the trips with at least one active lane, [4] those in which
+ * every active lane accepted the element, [5] those in which none did, [6] / [7] those of [4]
+ * / of the internal-node trips of [5] that follow from the bounding box of the group's 64
+ * targets alone (nearest corner already beyond the opening distance / farthest corner still
+ * inside it), [8] trips with all 64 lanes active; the rest zero */
+int psim_walk_profile(psim_context* ctx, int64_t out[16]);
+
 /* timing hook for benchmarks: average duration in milliseconds of `reps` launches of the
  * default walk kernel on the current tree with nothing else on the device (results go to
  * a scratch buffer).  slots_per_simd = 0 launches the whole grid at once; a value up to 8

@@ -933,6 +933,20 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
     uint32_t until = live ? 0u : 0xffffffffu;
     double ax = 0.0, ay = 0.0;
     uint32_t visits = 0, inter = 0, trips = 0, force_trips = 0;
+    // (counting launches only) how many trips are uniform over the group's active lanes, and how
+    // many of those could be told from the bounding box of the group's 64 targets alone
+    uint32_t uni_accept = 0, uni_open = 0, box_accept = 0, box_open = 0, full_trips = 0;
+    double bx0 = px, bx1 = px, by0 = py, by1 = py;
+    if (COUNT) {
+        const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+        const int first_live = live_mask ? __ffsll((long long)live_mask) - 1 : 0;
+        const double fx = __shfl(px, first_live, 64), fy = __shfl(py, first_live, 64);
+        if (!live) { bx0 = bx1 = fx; by0 = by1 = fy; }
+        for (int o = 32; o > 0; o >>= 1) {
+            bx0 = fmin(bx0, __shfl_xor(bx0, o, 64)); bx1 = fmax(bx1, __shfl_xor(bx1, o, 64));
+            by0 = fmin(by0, __shfl_xor(by0, o, 64)); by1 = fmax(by1, __shfl_xor(by1, o, 64));
+        }
+    }
     const double4_t* __restrict__ rec4 = reinterpret_cast<const double4_t*>(rec);
     uint32_t ju = 0;
     while (ju < total_elems) {
@@ -962,6 +976,18 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
         if (COUNT) {
             const unsigned long long take_mask = __builtin_amdgcn_ballot_w64(take);
             visits += active ? 1u : 0u; inter += take ? 1u : 0u; trips += 1u; force_trips += take_mask ? 1u : 0u;
+            const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
+            if (act_mask) {
+                uni_accept += take_mask == act_mask ? 1u : 0u;
+                uni_open += take_mask == 0ull ? 1u : 0u;
+                full_trips += act_mask == ~0ull ? 1u : 0u;
+                // nearest and farthest point of the box from the element's centre of mass
+                const double nx = fmax(fmax(bx0 - rv.y, rv.y - bx1), 0.0), ny = fmax(fmax(by0 - rv.z, rv.z - by1), 0.0);
+                const double wx = fmax(fabs(rv.y - bx0), fabs(rv.y - bx1)), wy = fmax(fabs(rv.z - by0), fabs(rv.z - by1));
+                const double sc = FOLD ? 1.0 : (leaf ? 1.0 : theta2);
+                box_accept += lhs < sc * fma(nx, nx, ny * ny) ? 1u : 0u;
+                box_open += (!leaf && !(lhs < sc * fma(wx, wx, wy * wy))) ? 1u : 0u;
+            }
         }
         if (take) {                                          // skipped as a whole when no lane accepts
             double f = mass_inv_r3(rv.x, d2 + softening);
@@ -990,6 +1016,11 @@ __global__ void __launch_bounds__(256) gravity_walk_wave_kernel(
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&counters[2], (unsigned long long)trips);
             atomicAdd(&counters[3], (unsigned long long)force_trips);
+            atomicAdd(&counters[4], (unsigned long long)uni_accept);
+            atomicAdd(&counters[5], (unsigned long long)uni_open);
+            atomicAdd(&counters[6], (unsigned long long)box_accept);
+            atomicAdd(&counters[7], (unsigned long long)box_open);
+            atomicAdd(&counters[8], (unsigned long long)full_trips);
         }
     }
 }

@@ -351,11 +351,11 @@ int64_t psim_explosion_events(psim_context* ctx, psim_explosion_event* buf, int6
     return k;
 }
 
-static void walk_counts_impl(psim_context* ctx, int64_t out[4])
+static void walk_counts_impl(psim_context* ctx, int64_t* out, int n_out)
 {
     use_device(ctx->device);
     psim::Sim* s = ctx->sim;
-    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int i = 0; i < n_out; ++i) out[i] = 0;
     if (!s->tree_valid || s->walk_n == 0) throw std::runtime_error("psim: no tree built yet");
     // the tree describes the particles it was built from: after a step that removed particles
     // by explosion that is more than the current count (the removed ones are still in it)
@@ -376,10 +376,7 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     unsigned long long h[32];
     psim::be::copy_d2h(s->st, h, cnt.p, 256);
     psim::be::sync(s->st);
-    out[0] = (int64_t)h[0];
-    out[1] = (int64_t)h[1];
-    out[2] = (int64_t)h[2];
-    out[3] = (int64_t)h[3];
+    for (int i = 0; i < n_out && i < 32; ++i) out[i] = (int64_t)h[i];
 #else
     psim::DevBuf<uint32_t> cnt;
     cnt.ensure(2);
@@ -391,13 +388,17 @@ static void walk_counts_impl(psim_context* ctx, int64_t out[4])
     psim::be::launch(s->st, tn, k);
     out[0] = cnt.p[0];
     out[1] = cnt.p[1];
-    out[2] = out[3] = 0;
 #endif
 }
 
 int psim_walk_counts(psim_context* ctx, int64_t out[4])
 {
-    PSIM_TRY(ctx && out, walk_counts_impl(ctx, out))
+    PSIM_TRY(ctx && out, walk_counts_impl(ctx, out, 4))
+}
+
+int psim_walk_profile(psim_context* ctx, int64_t out[16])
+{
+    PSIM_TRY(ctx && out, walk_counts_impl(ctx, out, 16))
 }
 
 static void time_walk_impl(psim_context* ctx, int32_t reps, double slots_per_simd, double* ms_avg)

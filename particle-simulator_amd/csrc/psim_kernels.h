@@ -1003,6 +1003,11 @@ struct ContactDetect {
     // all the same (it is a sum of cell populations)
     int32_t prune, r_max;
     double cell_size;
+    // margin > 0: pairs closer than contact distance + margin are collected as well.  They do
+    // not touch yet; as members of the solver's first hypothesis they cost a test when their
+    // turn comes and drop out if they still do not touch, and those that a push-apart before
+    // them brings into contact are there from the start instead of one iteration later.
+    double margin;
     // Every unordered candidate pair is examined once: in-cell pairs from the earlier
     // slot, cross-cell pairs from the cell that has the other one among its four
     // "forward" neighbours (E, SW, S, SE).  A contact is keyed from its lower-index
@@ -1025,7 +1030,7 @@ struct ContactDetect {
         // The comparisons are written so that a NaN coordinate keeps the cell.
         bool need_e = east, need_s = south, need_sw = south && west, need_se = south && east;
         if (prune) {
-            const double reach = (double)(mr + r_max) + 1e-6;
+            const double reach = (double)(mr + r_max) + margin + 1e-6;
             const double gap_e = (double)(cx + 1) * cell_size - px, gap_s = (double)(cy + 1) * cell_size - py;
             const double gap_w = px - (double)cx * cell_size;
             need_e = need_e && !(gap_e > reach);
@@ -1047,14 +1052,15 @@ struct ContactDetect {
             // of the two is "i" (the differences only change sign)
             double dx = o.x - px, dy = o.y - py;
             double d2 = dx * dx + dy * dy;
-            double md = (double)(mr + o.r);
-            if (d2 < md * md && d2 > 0) {
+            double md = (double)(mr + o.r) + margin;
+            // (with a margin a coinciding pair is collected too: it does not touch as it is,
+            // particle_system.py:217, but a push on one of the two would make it)
+            if (d2 < md * md && (d2 > 0 || margin > 0)) {
                 if (WRITE) out_keys[at + found] = pair_key(g, k, (uint32_t)b);
                 else if (found < (uint32_t)kDetectKept) first_pair[(size_t)kDetectKept * k + found] = (uint32_t)b;
                 ++found;
-            } else if (!WRITE && d2 == 0) {
-                aggregated_inc(coincident_counter);
             }
+            if (!WRITE && d2 == 0) aggregated_inc(coincident_counter);
         };
         auto sweep = [&](int32_t lo, int32_t hi) {
             for (int32_t b = lo; b < hi; b += 4) {
@@ -1436,18 +1442,31 @@ struct SegDisplacement {
     // digest and looks at every candidate pair around every touched slot again (the check
     // that the digests' shortcut never alters a contact list)
     int32_t all_changed;
+    // The digest covers the slot's hypothesised contacts that did touch (geo != 0): one that
+    // did not left the position as it was, so the slot's position at any place in the order
+    // is the same with and without it.
+    const double* geo;
+    // far_from >= 0 (first iteration of a sweep whose hypothesis holds every pair within contact
+    // distance + margin of the initial positions): a pair outside the hypothesis can only touch
+    // if its two slots moved by more than the margin together, so only slots that moved by
+    // more than far_from = margin / 2 (less a hair) have pairs to look at again; the pairs
+    // inside the hypothesis were all tested when their turn came.
+    double far_from;
     static PSIM_HD PSIM_FORCEINLINE uint64_t mix(uint64_t h)
     {
         h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
         return h;
     }
+    // digest of a slot none of whose hypothesised contacts touched (also what sig = 0, "no
+    // hypothesised contact at all", stands for: the slot is at its initial position throughout)
+    static constexpr uint64_t kAtRest = 0x9e3779b97f4a7c15ull;
     PSIM_HD void operator()(int64_t e) const
     {
         if (e == 0) { zero_word[0] = 0u; zero_word[5] = 0u; }
         uint32_t x = (uint32_t)(adj[e] >> 32);
         if (cseg[x] != (int32_t)e) return;
         double x0 = body[x].x, y0 = body[x].y, m = 0.0;
-        uint64_t digest = 0x9e3779b97f4a7c15ull;
+        uint64_t digest = kAtRest;
         for (int64_t k = e; k < n_adj && (uint32_t)(adj[k] >> 32) == x; ++k) {
             uint32_t h = (uint32_t)adj[k];
             int side = (hsi[h] == x) ? 0 : 1;
@@ -1455,6 +1474,7 @@ struct SegDisplacement {
             double dx = p.x - x0, dy = p.y - y0;
             double d2 = dx * dx + dy * dy;
             m = d2 > m ? d2 : m;
+            if (geo[3 * (size_t)h] == 0.0 && geo[3 * (size_t)h + 1] == 0.0) continue;      // did not touch
             uint64_t bx, by;
             __builtin_memcpy(&bx, &p.x, 8);
             __builtin_memcpy(&by, &p.y, 8);
@@ -1466,7 +1486,8 @@ struct SegDisplacement {
         double bound = sqrt(m) * (1.0 + 1e-6) + 1e-9;
         dseg[e] = bound;
         raise_to_u32(dmax_bits, float_bits_at_least(bound));
-        changed[x] = (all_changed || sig[x] != digest) ? 1 : 0;
+        if (far_from >= 0.0 && !all_changed) changed[x] = bound > far_from ? 1 : 0;
+        else changed[x] = (all_changed || (sig[x] ? sig[x] : kAtRest) != digest) ? 1 : 0;
         dsig[e] = digest;
     }
 };
@@ -1484,7 +1505,8 @@ struct MarkUntouched {
     {
         if (i >= (int64_t)*n_prev) return;
         uint32_t y = prev_slots[i];
-        if (cseg[y] < 0) { changed[y] = 1; sig[y] = 0; }
+        // (a slot whose hypothesised contacts all failed to touch never left its initial position)
+        if (cseg[y] < 0) { if (sig[y] != SegDisplacement::kAtRest) changed[y] = 1; sig[y] = 0; }
     }
 };
 
@@ -1510,7 +1532,7 @@ struct WorkFlags {
         if (i < n_adj) {
             if (i < (int64_t)*n_touched) f = changed[(uint32_t)(adj[touched[i]] >> 32)] ? 1u : 0u;
         } else if (i - n_adj < (int64_t)*n_prev) {
-            f = cseg[prev_slots[i - n_adj]] < 0 ? 1u : 0u;
+            f = (cseg[prev_slots[i - n_adj]] < 0 && changed[prev_slots[i - n_adj]]) ? 1u : 0u;
         }
         flags[i] = f;
     }
@@ -1683,7 +1705,7 @@ struct ContactRetest {
             which = (int)which_u;
             if (ti < (int64_t)*n_prev) {
                 x = prev_slots[ti];
-                work = cseg[x] < 0;              // no contact any more: at its initial position throughout
+                work = cseg[x] < 0 && changed[x] != 0;    // no contact any more: back at its initial position throughout
             }
         }
         uint32_t found = 0;
@@ -1752,13 +1774,15 @@ struct ContactCarry {
     const uint32_t* offsets;
     uint64_t* out_keys;
     int32_t write_pass;
+    const double* geo;         // [3h] of this iteration's execution: 0, 0 where the pair did not touch
     PSIM_HD void operator()(int64_t h) const
     {
         if (write_pass) {
             if (counts[h]) out_keys[offsets[h]] = hkeys[h];
             return;
         }
-        counts[h] = (changed[hsi[h]] == 0 && changed[hsj[h]] == 0) ? 1u : 0u;
+        const bool touched = geo[3 * (size_t)h] != 0.0 || geo[3 * (size_t)h + 1] != 0.0;
+        counts[h] = (touched && changed[hsi[h]] == 0 && changed[hsj[h]] == 0) ? 1u : 0u;
     }
 };
 

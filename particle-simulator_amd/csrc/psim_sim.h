@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include <stdexcept>
 #include <string>
 #include <algorithm>
@@ -582,7 +583,7 @@ public:
         pcount.ensure(c); poffs.ensure(c); first_key.ensure((size_t)kDetectKept * c / 2 + 1); scan_scratch.ensure_zero(s, be::scan_temp_words(c));
         be::dev_memset(s, ctr, 0, 64);
         ContactDetect d;
-        d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
+        d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size; d.margin = detect_margin();
         d.n = k_hi - k_lo; d.k0 = (uint32_t)k_lo; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = reinterpret_cast<uint32_t*>(first_key.p);
         d.out_keys = nullptr; d.write_pass = 0; d.cand_counter = cfg.debug ? ctr + 1 : nullptr;
         d.coincident_counter = ctr + 3;
@@ -912,6 +913,24 @@ public:
         if (bits > 64) throw std::runtime_error("psim: grid cell population too large for the pair-key layout");
         return bits;
     }
+    // How far beyond contact distance the first hypothesis of a sweep reaches (ContactDetect::margin).
+    // In a sparse state (the benchmark's uniform clouds: 2 % of the particles in contact) the
+    // hypothesis of the pairs that touch as they are is settled in three cheap iterations.  In a
+    // clumped state every push-apart brings the next pair of a packed clump into contact, and
+    // each of those is found one iteration late; with a margin they are in the hypothesis from
+    // the start.  Switched on by the previous step's share of particles in contact.
+    double margin_env = -2.0;
+    bool margin_on = false;
+    double sweep_margin = 0.0;         // the margin the current sweep's first hypothesis was made with
+    double detect_margin()
+    {
+        if (margin_env < -1.5) {
+            const char* e = getenv("PSIM_DETECT_MARGIN");
+            margin_env = e ? atof(e) : -1.0;
+        }
+        if (margin_env >= 0.0) return margin_env;      // (experiments)
+        return margin_on ? 1.0 : 0.0;
+    }
     // ContactDetect may skip forward cells by distance to the shared border only while the
     // slot records hold the positions the grid was built from (the step's first sweep)
     bool detect_prune = true;
@@ -919,6 +938,7 @@ public:
     void sweep_positions(const Lane& ln, int sweep)
     {
         if (sweep > 0) detect_prune = false;
+        sweep_margin = detect_margin();
         GridView g = grid_view();
         const int slot_field_bits = ceil_log2_u64((uint64_t)ns + 1);
         uint32_t* const ctr = ln.ctr;
@@ -936,7 +956,7 @@ public:
                 detect_count(ln.s, scan_scratch, ctr, ln.small_groups);
             }
             ContactDetect d;
-            d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size;
+            d.prune = detect_prune ? 1 : 0; d.r_max = max_radius; d.cell_size = (double)cfg.cell_size; d.margin = detect_margin();
             d.n = ns; d.k0 = 0; d.g = g; d.counts = pcount.p; d.offsets = poffs.p; d.first_pair = reinterpret_cast<uint32_t*>(first_key.p);
             d.coincident_counter = nullptr;
             uint32_t three[4];
@@ -1029,7 +1049,8 @@ public:
                 dseg.ensure(2 * (size_t)nH); dsig.ensure(2 * (size_t)nH);
                 auto displacement_and_changes = [&]() {
                     be::launch(ln.s, 2ll * nH, SegDisplacement{2ll * nH, adjs, cseg.p, hsi.p, outp.p, cbody.p, dseg.p, ctr + 7, ctr + 1,
-                                                               H, slot_sig.p, dsig.p, slot_changed.p, (cfg.debug & 4) ? 1 : 0});
+                                                               H, slot_sig.p, dsig.p, slot_changed.p, (cfg.debug & 4) ? 1 : 0, cgeo.p,
+                                                               (iter == 0 && sweep_margin > 0.0) ? 0.5 * sweep_margin - 1e-6 : -1.0});
                     if (cap_prev > 0)
                         be::launch(ln.s, cap_prev, MarkUntouched{cap_prev, prev_slots[prev_list].p, ctr + 9 + prev_list, cseg.p,
                                                                  slot_sig.p, slot_changed.p});
@@ -1074,7 +1095,7 @@ public:
                 r.work = large ? wlist.p : nullptr; r.n_work = n_work > 0 ? n_work : 1;
                 r.counts = pcount.p; r.offsets = poffs.p; r.first_key = first_key.p; r.out_keys = nullptr;
                 r.write_pass = 0;
-                rp.carry = ContactCarry{(int64_t)nH, H, hsi.p, hsj.p, slot_changed.p, pcount.p + nt, poffs.p + nt, nullptr, 0};
+                rp.carry = ContactCarry{(int64_t)nH, H, hsi.p, hsj.p, slot_changed.p, pcount.p + nt, poffs.p + nt, nullptr, 0, cgeo.p};
                 rp.pending = CountPending{(int64_t)nH, done.p, ctr + 1, ctr + 6};
                 rp.nt = nt; rp.n0 = nH;
                 for (;;) {
@@ -1510,6 +1531,11 @@ public:
     void begin_step()
     {
         timer.next_step();
+        // (n_contacts still holds the previous step's count)
+        if (n > 0) {
+            if (n_contacts * 10 > n) margin_on = true;
+            else if (n_contacts * 20 < n) margin_on = false;
+        }
         n_exploded = 0;
         last_exploded.clear();
         moved_valid = false;

@@ -21,7 +21,7 @@ STAGE_ALL = 31
 EXPORTS = [
     "psim_create", "psim_destroy", "psim_set_config", "psim_upload", "psim_download",
     "psim_num_particles", "psim_particle_updates", "psim_prime_gravity", "psim_step", "psim_energies",
-    "psim_collision_stats", "psim_counts", "psim_explosion_events", "psim_walk_counts",
+    "psim_collision_stats", "psim_counts", "psim_explosion_events", "psim_walk_counts", "psim_walk_profile",
     "psim_debug_size", "psim_debug_fetch", "psim_selftest", "psim_stage_times",
     "psim_last_error", "psim_version",
     "psim_stage_build", "psim_stage_gravity", "psim_stage_slab_positions", "psim_stage_kick",
@@ -101,6 +101,7 @@ def load(path=None):
     L.psim_explosion_events.argtypes = [vp, ctypes.POINTER(ExplosionEvent), ctypes.c_int64]
     L.psim_explosion_events.restype = ctypes.c_int64
     L.psim_walk_counts.argtypes = [vp, c_ip]
+    L.psim_walk_profile.argtypes = [vp, c_ip]
     L.psim_debug_size.argtypes = [vp, ctypes.c_char_p]
     L.psim_debug_size.restype = ctypes.c_int64
     L.psim_debug_fetch.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_size_t]

@@ -358,6 +358,15 @@ class ParticleSystem:
         self.last_walk_trips = (int(out[2]), int(out[3]))
         return int(out[0]), int(out[1])
 
+    def walk_profile(self):
+        """lane statistics of the walk's loop on the current tree (psim_walk_profile)"""
+        self._sync_state()
+        out = (ctypes.c_int64 * 16)()
+        _capi.check(self._lib, self._lib.psim_walk_profile(self._ctx, out))
+        keys = ("visits", "interactions", "trips", "force_trips", "uniform_accept_trips", "uniform_open_trips",
+                "box_accept_trips", "box_open_trips", "full_trips")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def time_walk(self, reps=3, slots_per_simd=0.0):
         """Average milliseconds of the default walk kernel on the current tree with the
         device to itself (0 = whole grid at once; else that many resident waves per SIMD)."""
