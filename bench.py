@@ -108,6 +108,49 @@ def cpu_baseline(n, bounds, state, primed_accelerations, mask, label):
                       "gcc -O2 with -ffast-math on the reference's fastmath stages, one thread" % (label, n)}
 
 
+def other_workload(name, steps, warmup, device, cpu_steps=0):
+    """One of the other single-GPU configurations, compact: the same timed loop as the main
+    measurement (all steps in one call of the library, state resident), the walk's share, and
+    for C0 -- the reference's own default run -- the oracle timed on the same state for
+    `cpu_steps` steps (prime, then update() that many times, as the reference's main.py does)."""
+    from psim_amd.particle_system import ParticleSystem
+    label, n, bounds, state, mask = workload(name)
+    ps = ParticleSystem(n, dict(SIM), np.random.default_rng(42), bounds, device=device, stage_mask=mask, state=state)
+    ps._calculate_gravity()
+    ps.update(warmup)
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ps.update(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    updates = ps.particle_updates()
+    stage_ms = ps.stage_times_ms()
+    visits, inter = ps.walk_counts()
+    flops = 20.0 * inter + 8.0 * (visits - inter)
+    walk_ms = stage_ms.get("gravity", 0.0)
+    rec = {"workload": label, "particles": n, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+           "value": updates / dt, "unit": "particle-updates/s", "walk_kernel_ms": walk_ms,
+           "walk_frac_of_fp64_valu_peak": (flops / (walk_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS) if walk_ms > 0 else 0.0,
+           "contacts_last_step": ps.counts()["contacts"]}
+    ps.close()
+    if cpu_steps:
+        from oracle import oracle as orc
+        o = orc.OracleSystem(n, SIM, np.random.default_rng(42), bounds, state=state, stage_mask=mask, fast_stages=True)
+        o.set_fast_pow(True)
+        o._calculate_gravity()
+        t0 = time.perf_counter()
+        done = 0
+        for _ in range(cpu_steps):
+            o.update()
+            done += o.num_particles
+        cdt = time.perf_counter() - t0
+        rec["cpu_baseline"] = {"value": done / cdt, "unit": "particle-updates/s", "cores": 1, "kind": "port", "seconds": cdt,
+                               "sample": "%d steps of the workload itself after priming, oracle/psim_oracle.c, gcc -O2 with "
+                                         "-ffast-math on the reference's fastmath stages, one thread" % cpu_steps}
+    return rec
+
+
 def launch_ranks(n_ranks):
     """Start one fresh process per rank (this process has not touched the GPU or imported
     torch) and hand rank 0's output through.  Returns the exit code."""
@@ -154,6 +197,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="the default single-GPU run also measures, compactly, the other single-GPU configurations "
+                         "(C0 with its CPU baseline, C1, C3 on one GPU): skip that")
     ap.add_argument("--walk-mode", type=int, default=0)
     ap.add_argument("--library", default=None,
                     help="alternative build of the library (kernel experiments; the test-only host-loop build, "
@@ -370,6 +416,14 @@ def main():
                                   "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                                   "frac": tf / PEAK_FP64_VALU_TFLOPS}
             bs.close()
+        if (world == 1 and on_gpu and emulate is None and not args.staged and args.workload is None and
+                args.library is None and not args.no_other_workloads):
+            # the other single-GPU configurations, so that the one line holds them all
+            ps.close()
+            out["other_workloads"] = {
+                "c0": other_workload("c0", 100, 10, local_rank, cpu_steps=0 if args.no_cpu_baseline else 100),
+                "c1": other_workload("c1", 20, 3, local_rank),
+                "c3_one_gpu": other_workload("c3", 10, 2, local_rank)}
         if want_cpu:      # (one rank only: the other ranks would wait at the barrier)
             ps.close()
             out["cpu_baseline"] = cpu_baseline(n, bounds, initial, primed, mask, label)

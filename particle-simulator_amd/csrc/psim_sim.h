@@ -961,6 +961,14 @@ public:
             d.coincident_counter = nullptr;
             uint32_t three[4];
             readback_on(ln, three, dctr, 16);
+            if (sweep == 0 && sweep_margin == 0.0 && margin_env < 0.0 && (int64_t)three[0] * 10 > ns) {
+                // a state this full of contacts on its first step (nothing to go by before): count again, with the margin
+                margin_on = true;
+                sweep_margin = detect_margin();
+                d.margin = sweep_margin;
+                detect_count(ln.s, scan_scratch, ctr, ln.small_groups);
+                readback_on(ln, three, ctr, 16);
+            }
             n0 = three[0]; cand = three[1];
             if (sweep == 0) n_coincident = three[3];
             set_slot_bits(three[2]);
@@ -1483,6 +1491,14 @@ public:
     // (FP64-bound) and not with the tree build (memory-bound like themselves).  Joined by
     // join_side_work().
     bool side_running = false;
+    // The side stream's head start for the walk: only when the walk fills the slots it is allowed
+    // (a walk of fewer chunks than that leaves room anyway, and 40 us is a tenth of a
+    // 2000-particle step)
+    void side_delay()
+    {
+        const int64_t chunks = (n + 127) / 128, resident = walk_resident_waves();
+        if (resident > 0 && chunks >= resident) be::delay(st2, 40);
+    }
     // The side work may start where the tree is built (timer mark 3); the walk and the kick are
     // launched first, and only then is the side work submitted: its launches would
     // otherwise sit between the tree build and the walk on the host's submission path, and
@@ -1494,7 +1510,7 @@ public:
         // side work earlier instead -- in front of the tree's last kernel, which is all latency --
         // was measured: whatever side kernel is running when the walk arrives keeps the walk's
         // persistent waves from being placed, and the step got 4 % slower)
-        be::delay(st2, 40);
+        side_delay();
         build_grid(st2, sort_tmp2);
         if (cfg.stage_mask & kStageCollisions) {
             detect_count(st2, scan_tmp2, counters2.p, true);
@@ -1652,7 +1668,7 @@ public:
         Lane ln = side ? side_lane() : main_lane();
         if (side) {
             be::stream_wait(st2, ev_release());
-            be::delay(st2, 40);      // (the walk's persistent waves take their slots first, see start_side_work)
+            side_delay();            // (the walk's persistent waves take their slots first, see start_side_work)
             side_running = true;
         }
         build_grid_band(ln, b);

@@ -8,10 +8,10 @@ cd $R
 step() { echo "== $*" >&2; }
 step bench lines
 timeout -k 10 400 python bench.py > $O/${P}_bench_c2.json 2> $O/bench_c2.err || exit 1
-timeout -k 10 200 python bench.py --no-cpu-baseline --brute 0 --workload c1 > $O/${P}_bench_c1.json 2> $O/bench_c1.err || exit 1
-timeout -k 10 200 python bench.py --no-cpu-baseline --brute 0 --workload c0 > $O/${P}_bench_c0.json 2> $O/bench_c0.err || exit 1
-timeout -k 10 300 python bench.py --no-cpu-baseline --brute 0 --workload c3 --steps 5 --warmup 2 > $O/${P}_bench_c3_single_gpu.json 2> $O/bench_c3.err || exit 1
-timeout -k 10 300 python bench.py --no-cpu-baseline --brute 0 --workload c3 --steps 5 --warmup 2 --staged > $O/${P}_bench_c3_staged_one_rank.json 2> $O/bench_c3s.err || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c1 > $O/${P}_bench_c1.json 2> $O/bench_c1.err || exit 1
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c0 > $O/${P}_bench_c0.json 2> $O/bench_c0.err || exit 1
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c3 --steps 5 --warmup 2 > $O/${P}_bench_c3_single_gpu.json 2> $O/bench_c3.err || exit 1
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c3 --steps 5 --warmup 2 --staged > $O/${P}_bench_c3_staged_one_rank.json 2> $O/bench_c3s.err || exit 1
 step walk alone by slots
 timeout -k 10 200 python tools/time_walk_slots.py > $O/${P}_walk_alone_by_slots.txt 2> $O/tw.err || exit 1
 step stress runs
@@ -21,17 +21,17 @@ timeout -k 10 300 python tools/big_smoke.py 67108864 2 > $O/${P}_smoke_64Mi_sing
 timeout -k 10 200 python tools/drift_report.py > $O/${P}_drift_c0.txt 2> $O/drift.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 step kernel stats
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --no-cpu-baseline --brute 0 > $O/stats.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -o c3 -- python3 $R/bench.py --no-cpu-baseline --brute 0 --workload c3 --steps 5 --warmup 2 > $O/stats3.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -o c3 -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c3 --steps 5 --warmup 2 > $O/stats3.log 2>&1 || exit 1
 step timelines
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/tl -o tl -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 5 > $O/tl.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/tl3 -o tl -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 3 --warmup 2 --workload c3 > $O/tl3.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/hb_t -o t -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 3 --warmup 2 --no-overlap > $O/hb_t.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/hb3_t -o t -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 3 --warmup 2 --no-overlap --workload c3 > $O/hb3_t.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/tl -o tl -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 5 > $O/tl.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/tl3 -o tl -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 3 --warmup 2 --workload c3 > $O/tl3.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/hb_t -o t -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 3 --warmup 2 --no-overlap > $O/hb_t.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/hb3_t -o t -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 3 --warmup 2 --no-overlap --workload c3 > $O/hb3_t.log 2>&1 || exit 1
 step counters
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format rocpd -d $O/hb_f -o f -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 3 --warmup 2 --no-overlap > $O/hb_f.log 2>&1 || exit 1
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format rocpd -d $O/hb_w -o w -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 3 --warmup 2 --no-overlap > $O/hb_w.log 2>&1 || exit 1
-timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format rocpd -d $O/pmc -o p -- python3 $R/bench.py --no-cpu-baseline --brute 0 --steps 2 --warmup 1 --no-overlap > $O/pmc.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format rocpd -d $O/hb_f -o f -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 3 --warmup 2 --no-overlap > $O/hb_f.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format rocpd -d $O/hb_w -o w -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 3 --warmup 2 --no-overlap > $O/hb_w.log 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format rocpd -d $O/pmc -o p -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 2 --warmup 1 --no-overlap > $O/pmc.log 2>&1 || exit 1
 cd $R
 db() { ls $O/$1/*/*.db $O/$1/*.db 2>/dev/null | head -1; }
 python3 tools/timeline.py $(db tl) > $O/${P}_step_timeline_c2.txt

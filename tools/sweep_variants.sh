@@ -7,7 +7,7 @@ mkdir -p $O
 cd $R
 for f in variants/libpsim_hip_*.so; do
   b=$(basename $f .so)
-  timeout -k 10 200 python bench.py --no-cpu-baseline --brute 0 --library $R/$f "$@" > $O/$b.json 2> $O/$b.err
+  timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-workloads --brute 0 --library $R/$f "$@" > $O/$b.json 2> $O/$b.err
 done
 python3 - "$O" <<'PY'
 import json, glob, sys
