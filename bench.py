@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-walk-alone", action="store_true",
+                    help="do not time the walk kernel with the device to itself after the steps (profiling runs: every "
+                         "launch of the kernel in the trace is then one of the steps' own, but for the priming call)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="the default single-GPU run also measures, compactly, the other single-GPU configurations "
                          "(C0 with its CPU baseline, C1, C3 on one GPU): skip that")
@@ -365,7 +368,7 @@ def main():
         # In the step the walk shares the device: it holds part of the wave slots and the
         # grid build and contact solver run in the rest.  The same kernel on the same tree
         # with the device to itself, for comparison:
-        alone_ms = ps.time_walk(3, 0.0) if (world == 1 and on_gpu and emulate is None) else None
+        alone_ms = ps.time_walk(3, 0.0) if (world == 1 and on_gpu and emulate is None and not args.no_walk_alone) else None
         out = {
             "metric": "particle-updates/sec", "value": updates / dt, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -373,8 +376,8 @@ def main():
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": label, "particles": n, "theta": SIM["barnes_hut_theta"],
-                       "multi_gpu": ("one simulation sharded over %d ranks: walk by sorted-target range, contact detection "
-                                     "and conduction by grid-slot slabs, RCCL all-gathers" % world) if world > 1 else
+                       "multi_gpu": ("one simulation sharded over %d ranks: walk by sorted-target range, collisions and conduction "
+                                     "by slabs of grid rows (own rows + halo, seam records verified), RCCL all-gathers" % world) if world > 1 else
                                      ("rank %d of %d played by one process (its compute share only)" % (emulate[1], emulate[0])
                                       if emulate is not None else
                                       "single (stage entry points of the sharded path, one rank)" if args.staged else "single")},
@@ -398,6 +401,8 @@ def main():
             out["emulated_rank"] = emulated
             out["roofline"]["note"] = "walk kernel time is not separated in this mode (see ms_per_step_by_piece)"
         if world > 1:
+            out["sharding"] = {"rows": ps._row_bounds, "halo_rows": ps._halo, "whole_grid_fallbacks": ps.fallbacks,
+                               "exchange_bytes": ps.exchange_bytes}
             out["roofline"]["kernel_ms_per_rank"] = walk_ms_ranks
             out["roofline"]["frac_per_rank"] = [flops / (m * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS if m > 0 else 0.0
                                                 for m in walk_ms_ranks]

@@ -294,6 +294,10 @@ class ShardedParticleSystem(ParticleSystem):
                     _capi.check(L, L.psim_stage_apply(ctx, ctypes.c_void_p(self._blocks.data_ptr()), W, self._block_words,
                                                       ctypes.byref(status), self._own_slots, ctypes.byref(most)))
                 if status.value != 2:
+                    # (blocks much larger than the step needed shrink, on all ranks alike: the
+                    # whole block travels, whatever it holds)
+                    if int(most.value) * 3 + 16384 < self._block_words:
+                        self._alloc_blocks(int(most.value) * 3 // 2 + 4096)
                     break
                 # some rank's block did not fit: all ranks grow alike and export again
                 self._alloc_blocks(int(most.value) * 5 // 4 + 4096)

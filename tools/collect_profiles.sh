@@ -1,8 +1,8 @@
-# The measurement set kept under profiles/ (written under gpurun_out/r2prof and copied from there).
+# The measurement set kept under profiles/ (written under gpurun_out/r3prof and copied from there).
 # usage (on the GPU box): bash tools/collect_profiles.sh
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2prof
-P=r2
+O=$R/gpurun_out/r3prof
+P=r3
 mkdir -p $O
 cd $R
 step() { echo "== $*" >&2; }
@@ -12,6 +12,14 @@ timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-workloads --brute
 timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c0 > $O/${P}_bench_c0.json 2> $O/bench_c0.err || exit 1
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c3 --steps 5 --warmup 2 > $O/${P}_bench_c3_single_gpu.json 2> $O/bench_c3.err || exit 1
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c3 --steps 5 --warmup 2 --staged > $O/${P}_bench_c3_staged_one_rank.json 2> $O/bench_c3s.err || exit 1
+step one rank of eight
+for r in 0 3 7; do
+timeout -k 10 300 python bench.py --emulate-rank $r --world 8 --steps 5 --warmup 2 > $O/${P}_bench_c3_rank${r}_of_8_emulated.json 2> $O/emu$r.err || exit 1
+done
+timeout -k 10 300 python bench.py --emulate-rank 1 --world 2 --steps 5 --warmup 2 > $O/${P}_bench_c3_rank1_of_2_emulated.json 2> $O/emu2.err || exit 1
+timeout -k 10 300 python bench.py --emulate-rank 1 --world 4 --steps 5 --warmup 2 > $O/${P}_bench_c3_rank1_of_4_emulated.json 2> $O/emu4.err || exit 1
+step walk lane profile
+timeout -k 10 200 python tools/walk_profile.py c2 > $O/${P}_walk_lane_profile_c2.json 2> $O/wp.err || exit 1
 step walk alone by slots
 timeout -k 10 200 python tools/time_walk_slots.py > $O/${P}_walk_alone_by_slots.txt 2> $O/tw.err || exit 1
 step stress runs
@@ -21,8 +29,8 @@ timeout -k 10 300 python tools/big_smoke.py 67108864 2 > $O/${P}_smoke_64Mi_sing
 timeout -k 10 200 python tools/drift_report.py > $O/${P}_drift_c0.txt 2> $O/drift.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 step kernel stats
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 > $O/stats.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -o c3 -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --workload c3 --steps 5 --warmup 2 > $O/stats3.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --no-walk-alone --brute 0 > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -o c3 -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --no-walk-alone --brute 0 --workload c3 --steps 5 --warmup 2 > $O/stats3.log 2>&1 || exit 1
 step timelines
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/tl -o tl -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 5 > $O/tl.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/tl3 -o tl -- python3 $R/bench.py --no-cpu-baseline --no-other-workloads --brute 0 --steps 3 --warmup 2 --workload c3 > $O/tl3.log 2>&1 || exit 1
