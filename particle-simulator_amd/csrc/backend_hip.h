@@ -274,10 +274,38 @@ constexpr int kScanTileSmall = kScanThreadsSmall * kScanItems;
 // before its first use.
 constexpr uint64_t kScanLocal = 1ull << 62, kScanInclusive = 2ull << 62, kScanValue = (1ull << 62) - 1;
 
-template <int kScanThreads>
+// What is scanned and what becomes of the result.  PlainScan: the words of `in`, the exclusive
+// prefix written to `out`.  Another policy can compute its item from something else and use
+// the prefix as the place of a compacted record (BandSelect below): one pass over the input
+// where flag, scan and write would be three, each with its own array in between.
+struct PlainScan {
+    static constexpr bool kPlain = true;
+    __device__ __forceinline__ uint32_t item(const uint32_t* in, uint32_t i) const { return in[i]; }
+    __device__ __forceinline__ void put(uint32_t* out, uint32_t i, uint32_t, uint32_t prefix) const { out[i] = prefix; }
+};
+// The particles whose grid cell lies in the rows [row_lo, row_hi): their cells (relative to the
+// band's first) and indices, in ascending particle order.
+struct BandSelect {
+    static constexpr bool kPlain = false;
+    int32_t gw, row_lo, row_hi;
+    uint32_t cell_base;
+    uint32_t* key_out;
+    uint32_t* perm_out;
+    __device__ __forceinline__ uint32_t item(const uint32_t* cell, uint32_t i) const
+    {
+        const int32_t row = (int32_t)(cell[i] / (uint32_t)gw);
+        return (row >= row_lo && row < row_hi) ? 1u : 0u;
+    }
+    __device__ __forceinline__ void put(uint32_t*, uint32_t i, uint32_t value, uint32_t prefix, const uint32_t* cell) const
+    {
+        if (value) { key_out[prefix] = cell[i] - cell_base; perm_out[prefix] = i; }
+    }
+};
+
+template <int kScanThreads, class Op = PlainScan>
 __global__ void __launch_bounds__(kScanThreads) scan_lookback_kernel(const uint32_t* in, uint32_t* out, uint32_t n,
                                                                      uint32_t ntiles, uint32_t* temp, uint32_t* total_out,
-                                                                     uint32_t* fault)
+                                                                     uint32_t* fault, Op op = Op())
 {
     constexpr int kScanTile = kScanThreads * kScanItems;
     __shared__ uint32_t wsum[17];
@@ -292,7 +320,7 @@ __global__ void __launch_bounds__(kScanThreads) scan_lookback_kernel(const uint3
     uint32_t v[kScanItems];
     uint32_t sum = 0;
     const bool full = base + kScanItems <= n && base + kScanItems > base;
-    if (full) {
+    if (full && Op::kPlain) {
         const uint4* p = reinterpret_cast<const uint4*>(in + base);
 #pragma unroll
         for (int i = 0; i < kScanItems / 4; ++i) {
@@ -301,7 +329,7 @@ __global__ void __launch_bounds__(kScanThreads) scan_lookback_kernel(const uint3
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < kScanItems; ++i) v[i] = (base + i < n) ? in[base + i] : 0u;
+        for (int i = 0; i < kScanItems; ++i) v[i] = (base + i < n) ? op.item(in, base + i) : 0u;
     }
 #pragma unroll
     for (int i = 0; i < kScanItems; ++i) sum += v[i];
@@ -366,13 +394,20 @@ __global__ void __launch_bounds__(kScanThreads) scan_lookback_kernel(const uint3
     ex += (uint32_t)s_before;
 #pragma unroll
     for (int i = 0; i < kScanItems; ++i) { uint32_t t = v[i]; v[i] = failed ? 0u : ex; ex += t; }
-    if (full) {
-        uint4* p = reinterpret_cast<uint4*>(out + base);
+    if constexpr (Op::kPlain) {
+        if (full) {
+            uint4* p = reinterpret_cast<uint4*>(out + base);
 #pragma unroll
-        for (int i = 0; i < kScanItems / 4; ++i) p[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            for (int i = 0; i < kScanItems / 4; ++i) p[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kScanItems; ++i) if (base + i < n) out[base + i] = v[i];
+        }
     } else {
+        // (v[i] now holds the prefix; the item is the difference to the next prefix)
 #pragma unroll
-        for (int i = 0; i < kScanItems; ++i) if (base + i < n) out[base + i] = v[i];
+        for (int i = 0; i < kScanItems; ++i)
+            if (base + i < n && !failed) op.put(out, base + i, (i + 1 < kScanItems ? v[i + 1] : ex) - v[i], v[i], in);
     }
     // the last workgroup to get here clears the scratch for the next scan: by then every
     // workgroup has finished looking back, so no status word is read any more
@@ -443,6 +478,28 @@ inline void exclusive_scan_u32(Stream st, const uint32_t* in, uint32_t* out, uin
     }
     PSIM_HIP(hipGetLastError());
 }
+
+// The particles of a band of grid rows, compacted in one pass (see BandSelect): key_out / perm_out
+// receive their relative cells and indices, *total_out their number.  n > kScanSmall.
+inline void band_select(Stream st, const uint32_t* cell, uint64_t n, int32_t gw, int32_t row_lo, int32_t row_hi,
+                        uint32_t cell_base, uint32_t* key_out, uint32_t* perm_out, uint32_t* temp, uint32_t* total_out,
+                        bool small_groups)
+{
+    if (n > 0xfffffff0ull) throw std::runtime_error("band_select: too many items");
+    BandSelect op{gw, row_lo, row_hi, cell_base, key_out, perm_out};
+    if (small_groups) {
+        uint32_t nb = (uint32_t)((n + kScanTileSmall - 1) / kScanTileSmall);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_lookback_kernel<kScanThreadsSmall, BandSelect>), dim3(nb), dim3(kScanThreadsSmall),
+                           0, st, cell, (uint32_t*)nullptr, (uint32_t)n, nb, temp, total_out, lookback_fault_word(), op);
+    } else {
+        const uint32_t tile = 1024u * kScanItems;
+        uint32_t nb = (uint32_t)((n + tile - 1) / tile);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_lookback_kernel<1024, BandSelect>), dim3(nb), dim3(1024), 0, st, cell,
+                           (uint32_t*)nullptr, (uint32_t)n, nb, temp, total_out, lookback_fault_word(), op);
+    }
+    PSIM_HIP(hipGetLastError());
+}
+constexpr bool kHasBandSelect = true;
 
 // ------------------------------------------------------------------ radix sort (LSD, 8-bit digits)
 // One launch per digit pass ("one sweep"): a first kernel counts, for every pass at

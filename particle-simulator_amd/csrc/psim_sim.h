@@ -542,11 +542,21 @@ public:
         full_grid_valid = false;
         offsets.ensure((size_t)cfg.grid_w * (size_t)cfg.grid_h + 1);
         ns = 0;
+        // One pass where the input is long (the band's particles picked and compacted by a scan
+        // whose items are computed from the cell ids; the output arrays then have to hold up to n
+        // entries, the band's size not being known before), flag / scan / write kernels otherwise.
+        const bool one_pass = be::kHasBandSelect && (uint64_t)n > (uint64_t)be::kScanSmall;
         if (n > 0) {
-            bflag.ensure(c); bat.ensure(c);
             ln.scan_tmp->ensure_zero(ln.s, be::scan_temp_words(c));
-            be::launch(ln.s, n, BandFlag{n, ckey[0].p, cfg.grid_w, b.row_lo, b.row_hi, bflag.p});
-            be::exclusive_scan_u32(ln.s, bflag.p, bat.p, (uint64_t)n, ln.scan_tmp->p, ln.ctr + 12, small_groups_now(ln.small_groups));
+            if (one_pass) {
+                rkey[0].ensure(c); rkey[1].ensure(c); rperm[0].ensure(c); rperm[1].ensure(c);
+                be::band_select(ln.s, ckey[0].p, (uint64_t)n, cfg.grid_w, b.row_lo, b.row_hi, cell_base, rkey[0].p, rperm[0].p,
+                                ln.scan_tmp->p, ln.ctr + 12, small_groups_now(ln.small_groups));
+            } else {
+                bflag.ensure(c); bat.ensure(c);
+                be::launch(ln.s, n, BandFlag{n, ckey[0].p, cfg.grid_w, b.row_lo, b.row_hi, bflag.p});
+                be::exclusive_scan_u32(ln.s, bflag.p, bat.p, (uint64_t)n, ln.scan_tmp->p, ln.ctr + 12, small_groups_now(ln.small_groups));
+            }
             ns = read_u32(ln, ln.ctr + 12);
         }
         if (ns == 0) {
@@ -554,8 +564,10 @@ public:
             return;
         }
         const size_t cs = (size_t)ns;
-        rkey[0].ensure(cs); rkey[1].ensure(cs); rperm[0].ensure(cs); rperm[1].ensure(cs);
-        be::launch(ln.s, n, BandCompact{n, ckey[0].p, bflag.p, bat.p, cell_base, rkey[0].p, rperm[0].p});
+        if (!one_pass) {
+            rkey[0].ensure(cs); rkey[1].ensure(cs); rperm[0].ensure(cs); rperm[1].ensure(cs);
+            be::launch(ln.s, n, BandCompact{n, ckey[0].p, bflag.p, bat.p, cell_base, rkey[0].p, rperm[0].p});
+        }
         ln.sort_tmp->ensure(be::sort_temp_words(cs));
         uint32_t* k[2] = {rkey[0].p, rkey[1].p};
         uint32_t* v[2] = {rperm[0].p, rperm[1].p};

@@ -296,8 +296,9 @@ class ShardedParticleSystem(ParticleSystem):
                 if status.value != 2:
                     # (blocks much larger than the step needed shrink, on all ranks alike: the
                     # whole block travels, whatever it holds)
-                    if int(most.value) * 3 + 16384 < self._block_words:
-                        self._alloc_blocks(int(most.value) * 3 // 2 + 4096)
+                    self.exchange_bytes["block_sent_per_rank"] = 8 * self._block_words
+                    if int(most.value) * 6 + 16384 < self._block_words:
+                        self._alloc_blocks(int(most.value) * 3 + 4096)
                     break
                 # some rank's block did not fit: all ranks grow alike and export again
                 self._alloc_blocks(int(most.value) * 5 // 4 + 4096)

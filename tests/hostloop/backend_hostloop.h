@@ -70,6 +70,14 @@ inline void exclusive_scan_u32(Stream, const uint32_t* in, uint32_t* out, uint64
     if (total_out) *total_out = run;
 }
 
+constexpr uint32_t kScanSmall = 0xffffffffu;     // (this back end always takes the flag / scan / write kernels)
+constexpr bool kHasBandSelect = false;
+inline void band_select(Stream, const uint32_t*, uint64_t, int32_t, int32_t, int32_t, uint32_t, uint32_t*, uint32_t*,
+                        uint32_t*, uint32_t*, bool)
+{
+    throw std::runtime_error("band_select: not in the host-loop build");
+}
+
 inline size_t sort_temp_words(uint64_t) { return 1; }
 inline uint32_t* lookback_fault_word() { static uint32_t zero = 0; return &zero; }
 template <class KeyT>
