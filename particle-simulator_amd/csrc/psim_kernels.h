@@ -394,49 +394,45 @@ struct HilbertOrder {
 
 // Second half of the Morton sort.  The radix passes order the keys by their leading
 // bits only (key >> shift: enough levels that few particles share them); particles
-// that do share them form short runs, which the lane at each run's start finishes by
-// ranking on the full key (ties keep input order, like the stable radix passes).  A
-// run longer than kMaxFixRun is copied as is and reported, and the caller completes
-// the sort with the remaining radix passes.
+// that do share them form short runs, which the lane at each run's start finishes in
+// place by a stable insertion on the full key (ties keep their order, like the stable
+// radix passes).  A run longer than kMaxFixRun is left as it is and reported, and the
+// caller completes the sort with the remaining radix passes.  In place: nothing is
+// written where no run needs it (three quarters of the particles are alone in their
+// cell of that depth); the lanes that decide whether they start a run look at leading
+// bits only, which no reordering inside a run changes.
 // (Doing the gather into sorted order in this pass as well -- whoever places a particle index
 // fetches that particle's record -- was measured: 164 us against 46 + 94 for the two kernels,
 // the lanes that finish a run fetch serially while the others of the run idle.)
 constexpr uint32_t kMaxFixRun = 48;
 struct FixRuns {
     int64_t n;
-    const uint64_t* key_in;
-    const uint32_t* perm_in;
-    uint64_t* key_out;
-    uint32_t* perm_out;
+    uint64_t* key;
+    uint32_t* perm;
     uint32_t* overflow;
     int shift;
     PSIM_HD void operator()(int64_t s) const
     {
-        uint64_t k0 = key_in[s];
-        uint64_t hi = k0 >> shift;
-        if (s > 0 && (key_in[s - 1] >> shift) == hi) return;
+        uint64_t hi = key[s] >> shift;
+        if (s > 0 && (key[s - 1] >> shift) == hi) return;
         int64_t e = s + 1;
-        while (e < n && (key_in[e] >> shift) == hi) ++e;
+        while (e < n && (key[e] >> shift) == hi) ++e;
         int64_t r = e - s;
-        if (r == 1) {
-            key_out[s] = k0;
-            perm_out[s] = perm_in[s];
-            return;
-        }
+        if (r == 1) return;
         if (r > (int64_t)kMaxFixRun) {
-            for (int64_t i = s; i < e; ++i) { key_out[i] = key_in[i]; perm_out[i] = perm_in[i]; }
             *overflow = 1u;
             return;
         }
-        for (int64_t i = s; i < e; ++i) {
-            uint64_t ki = key_in[i];
-            int64_t rank = 0;
-            for (int64_t j = s; j < e; ++j) {
-                uint64_t kj = key_in[j];
-                rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+        for (int64_t i = s + 1; i < e; ++i) {
+            const uint64_t ki = key[i];
+            const uint32_t pi = perm[i];
+            int64_t j = i;
+            while (j > s && key[j - 1] > ki) {
+                key[j] = key[j - 1];
+                perm[j] = perm[j - 1];
+                --j;
             }
-            key_out[s + rank] = ki;
-            perm_out[s + rank] = perm_in[i];
+            if (j != i) { key[j] = ki; perm[j] = pi; }
         }
     }
 };

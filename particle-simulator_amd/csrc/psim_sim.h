@@ -685,9 +685,8 @@ public:
                 if (lead > 64) lead = 64;
                 int half = be::radix_sort_pairs<uint64_t>(st, k, v, (uint64_t)n, 64 - lead, 64, sort_tmp.p);
                 be::dev_memset(st, counters.p + 4, 0, 4);
-                be::launch(st, n, FixRuns{n, key[half].p, perm[half].p, key[half ^ 1].p, perm[half ^ 1].p, counters.p + 4,
-                                          lead < 64 ? 64 - lead : 0});
-                sorted_key = half ^ 1;
+                be::launch(st, n, FixRuns{n, key[half].p, perm[half].p, counters.p + 4, lead < 64 ? 64 - lead : 0});
+                sorted_key = half;
             } else {
                 // a long run of near-coincident particles was left unsorted: full LSD sort
                 be::dev_memset(st, counters.p + 4, 0, 4);      // (the kernels below look at this word)
