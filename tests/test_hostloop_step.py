@@ -177,3 +177,39 @@ def test_tight_pairs_tree_vs_oracle():
     n, bounds = 8000, (2000.0, 1000.0)
     st = parity.tight_pairs_state(n, bounds, 3, pairs=160, gap=1e-4, box=20.0)
     parity.check_tree_against_oracle(HOSTLOOP, st, n, bounds, expect_path=2)
+
+
+def test_reference_attributes_and_the_diagnostic_getters():
+    """`grid_offsets` / `grid_indices` / `qtree.boundary` as the reference's attributes
+    (particle_system.py:393-401): zeros before the first step, afterwards the CSR grid of the particles
+    the step started with; update counts and stage times of a multi-step call; the lane statistics of
+    the walk add up"""
+    n, bounds = 1500, (900, 600)
+    s = ParticleSystem(n, dict(SIM), np.random.default_rng(8), bounds, library=HOSTLOOP)
+    cells = s.grid_width * s.grid_height
+    assert s.grid_offsets.shape == (cells + 1,) and not s.grid_offsets.any()
+    assert s.grid_indices.shape == (n,) and not s.grid_indices.any()
+    box = s.qtree.boundary
+    assert (box.x, box.y, box.width, box.height) == (0, 0, bounds[0], bounds[1])
+    s._calculate_gravity()
+    s.update()
+    off, idx = s.grid_offsets, s.grid_indices
+    assert off[0] == 0 and off[-1] == n and np.all(np.diff(off) >= 0)
+    assert sorted(idx.tolist()) == list(range(n))
+    with pytest.raises(ValueError):
+        off[0] = 1
+    cell_of = np.repeat(np.arange(cells), np.diff(off))
+    assert cell_of.shape == (n,)
+    for k in range(0, n, 97):
+        members = idx[off[cell_of[k]]:off[cell_of[k] + 1]]
+        assert np.all(np.diff(members) > 0)                  # ascending particle index inside a cell
+    s.update(3)
+    assert s.particle_updates() == 3 * s.num_particles
+    t = s.stage_times_ms()
+    assert set(t) >= {"tree", "gravity", "collisions"} and all(v >= 0.0 for v in t.values())
+    p = s.walk_profile()
+    visits, inter = s.walk_counts()
+    assert (p["visits"], p["interactions"]) == (visits, inter)
+    assert p["uniform_accept_trips"] + p["uniform_open_trips"] + p["box_accept_trips"] + p["box_open_trips"] \
+        + p["full_trips"] <= p["trips"]
+    s.close()
