@@ -268,8 +268,8 @@ def main():
     from psim_amd.particle_system import ParticleSystem
     # N = 1: C2 (4Mi, the single-GPU configuration the metric is quoted on).
     # N > 1: C3 (16Mi rotating disk), ONE simulation sharded over the N ranks: every
-    # rank holds the state, gravity is split by sorted-target range, contact detection and
-    # conduction by grid-slot range, outputs all-gathered over RCCL (psim_amd/distributed.py).
+    # rank holds the state, gravity is split by sorted-target range, collisions and conduction
+    # by slabs of grid rows, results all-gathered over RCCL (psim_amd/distributed.py).
     wl = args.workload or ("c2" if world == 1 and emulate is None else "c3")
     label, n, bounds, state, mask = workload(wl)
     if world > 1 or args.staged:
@@ -290,6 +290,8 @@ def main():
     primed = ps.accelerations.copy() if want_cpu else None
     for _ in range(args.warmup):
         ps.update()
+    if world > 1:
+        ps.warm_up_exchanges()       # (with --warmup 0 the collectives' first use would be timed)
     if emulate is not None:
         ps.emulated_ms = {}
 

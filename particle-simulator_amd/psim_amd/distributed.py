@@ -203,6 +203,19 @@ class ShardedParticleSystem(ParticleSystem):
         dist.all_gather_into_tensor(self._blocks, self._block, group=self._group)
         self._sync()
 
+    def warm_up_exchanges(self):
+        """one all-gather of each kind on the step's own buffers (both are scratch between steps),
+        so that a backend's set-up on first use (communicator, channels, registration of the
+        buffers) is not inside the first timed step.  All ranks call it together."""
+        if self._world == 1 or self._emulate is not None:
+            return
+        _, _, per = shard_range(self.num_particles, 0, self._world)
+        work = self._gather_acc_start(per)
+        if work is not None:
+            work.wait()
+        self._gather_blocks()
+        self._sync()
+
     # ------------------------------------------------------------------ pieces of a step
     def _export(self, rank):
         """the current band's block -> self._block (real ranks) / its place in self._blocks (emulation)"""

@@ -65,6 +65,8 @@ def main():
             # needs and write nothing else, psim_stage_apply must say so on every rank, and the
             # step must succeed once all ranks have made room
             sh._alloc_blocks(32)
+        if step == 3:
+            sh.warm_up_exchanges()      # (between two steps the exchange buffers are scratch)
         sh.update()
         w = want[step - 1]
         assert w["n"] == sh.num_particles, (step, rank)
