@@ -15,41 +15,7 @@
 namespace psim {
 
 // --------------------------------------------------------------- helpers
-#if defined(PSIM_HOSTLOOP)
-inline uint32_t atomic_inc_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
-inline int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
-#else
-__device__ __forceinline__ uint32_t atomic_inc_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
-__device__ __forceinline__ int clz64(uint64_t x) { return x ? __clzll((long long)x) : 64; }
-#endif
-
-// add 1 to *p for every calling lane; one atomic per wave (the lanes that reach
-// this call together are counted by ballot and the first of them adds the sum)
-#if defined(PSIM_HOSTLOOP)
-inline void aggregated_inc(uint32_t* p) { *p += 1; }
-#else
-__device__ __forceinline__ void aggregated_inc(uint32_t* p)
-{
-    unsigned long long m = __ballot(1);
-    int lane = (int)(threadIdx.x & 63u);
-    if (lane == __ffsll((long long)m) - 1) atomicAdd(p, (uint32_t)__popcll(m));
-}
-#endif
-
-// *p = max(*p, v).  The current value is looked at first and the atomic only issued by lanes
-// that would raise it: a maximum over many lanes then costs a handful of atomics, not one
-// same-address atomic per wave (a stale look only costs a needless atomic).
-#if defined(PSIM_HOSTLOOP)
-inline void raise_to_u32(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
-#else
-__device__ __forceinline__ void raise_to_u32(uint32_t* p, uint32_t v)
-{
-    // a plain (cacheable, possibly stale) look first: most lanes stop there
-    if (v > *reinterpret_cast<volatile uint32_t*>(p) &&
-        v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(p, v);
-}
-#endif
+// (atomic_inc_u32, clz64, aggregated_inc, raise_to_u32, fill_run_i32, wave_max_store: lane_hip.h)
 
 // quadtree.py:13-19 (_get_quadrant) + :24-38,62-63 (child boxes, centre = x + w/2):
 // descend 32 levels from the root box exactly as an insertion would, recording
@@ -143,28 +109,7 @@ struct SegmentOffsets {
     {
         int64_t lo = (k == 0) ? 0 : (int64_t)keys[k - 1] + 1;
         int64_t hi = (k == n) ? (int64_t)num_segments : (int64_t)keys[k];
-#if defined(PSIM_HOSTLOOP)
-        for (int64_t c = lo; c <= hi; ++c) offsets[c] = (int32_t)k;
-#else
-        // A long run of empty segments before k (whole empty grid rows around a disk of
-        // particles: tens of thousands of cells) is filled by the 64 lanes of the wave together;
-        // one lane alone would keep its wave alive for as many stores.
-        constexpr int64_t kOwn = 16;
-        const bool far = hi - lo >= kOwn;
-        if (!far) for (int64_t c = lo; c <= hi; ++c) offsets[c] = (int32_t)k;
-        // (the lanes that run this body may be fewer than 64 in the last wave of the launch)
-        const unsigned long long here = __ballot(1);
-        unsigned long long todo = __ballot(far);
-        const int lane = (int)(threadIdx.x & 63u);
-        const int rank = __popcll(here & ((1ull << lane) - 1ull)), width = __popcll(here);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int64_t l2 = (int64_t)__shfl((long long)lo, src, 64), h2 = (int64_t)__shfl((long long)hi, src, 64);
-            const int32_t v = (int32_t)__shfl((long long)k, src, 64);
-            for (int64_t c = l2 + rank; c <= h2; c += width) offsets[c] = v;
-        }
-#endif
+        fill_run_i32(offsets, lo, hi, (int32_t)k);
     }
 };
 
@@ -192,16 +137,7 @@ struct WaveMaxOccupancy {
     PSIM_HD void operator()(int64_t c) const
     {
         uint32_t occ = c < cells ? (uint32_t)(offsets[c + 1] - offsets[c]) : 0u;
-#if defined(PSIM_HOSTLOOP)
-        if ((c & 63) == 0) wave_max[c >> 6] = 0;
-        if (occ > wave_max[c >> 6]) wave_max[c >> 6] = occ;
-#else
-        for (int o = 32; o > 0; o >>= 1) {
-            uint32_t t = (uint32_t)__shfl_xor((int)occ, o, 64);
-            occ = t > occ ? t : occ;
-        }
-        if ((c & 63) == 0) wave_max[c >> 6] = occ;
-#endif
+        wave_max_store(occ, (c & 63) == 0, &wave_max[c >> 6]);
     }
 };
 struct WaveMaxU32 {        // launched over count rounded up to whole waves
@@ -211,16 +147,7 @@ struct WaveMaxU32 {        // launched over count rounded up to whole waves
     PSIM_HD void operator()(int64_t c) const
     {
         uint32_t v = c < count ? in[c] : 0u;
-#if defined(PSIM_HOSTLOOP)
-        if ((c & 63) == 0) out[c >> 6] = 0;
-        if (v > out[c >> 6]) out[c >> 6] = v;
-#else
-        for (int o = 32; o > 0; o >>= 1) {
-            uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
-            v = t > v ? t : v;
-        }
-        if ((c & 63) == 0) out[c >> 6] = v;
-#endif
+        wave_max_store(v, (c & 63) == 0, &out[c >> 6]);
     }
 };
 struct FinalMax {          // launched over exactly 64 elements
@@ -231,16 +158,7 @@ struct FinalMax {          // launched over exactly 64 elements
     {
         uint32_t m = 0;
         for (int64_t i = lane; i < count; i += 64) { uint32_t v = wave_max[i]; m = v > m ? v : m; }
-#if defined(PSIM_HOSTLOOP)
-        if (lane == 0) *out = 0;
-        if (m > *out) *out = m;
-#else
-        for (int o = 32; o > 0; o >>= 1) {
-            uint32_t t = (uint32_t)__shfl_xor((int)m, o, 64);
-            m = t > m ? t : m;
-        }
-        if (lane == 0) *out = m;
-#endif
+        wave_max_store(m, lane == 0, out);
     }
 };
 

@@ -1050,12 +1050,8 @@ public:
                     sm.n = nH; sm.hsi = hsi.p; sm.hsj = hsj.p; sm.prev = prevl.p; sm.done = done.p; sm.round = round;
                     sm.out = outp.p; sm.geo = cgeo.p; sm.body = cbody.p;
                     sm.mass = mass.p; sm.G = cfg.gravity_constant; sm.soft = cfg.softening; sm.pos_correct = cfg.pos_correct;
-#if defined(PSIM_HOSTLOOP)
-                    be::launch(ln.s, nH, sm);
-#else
                     // (a launch carries the chains inside each tile of contacts as far as they go)
                     be::launch_contact_rounds<true>(ln.s, sm, nH, prevl.p, done.p, round, round_tile_view());
-#endif
                 }
                 solver_rounds += count;
             };
@@ -1192,13 +1188,11 @@ public:
     }
 
     // velocity half of the sweep whose position half ran last (main stream)
-#if !defined(PSIM_HOSTLOOP)
     be::RoundTiles round_tile_view() const
     {
         const size_t t = round_tiles.cap / 3;
         return be::RoundTiles{round_tiles.p, round_tiles.p + t, round_tiles.p + 2 * t};
     }
-#endif
 
     void sweep_velocities(int sweep)
     {
@@ -1210,11 +1204,7 @@ public:
             v.geo = cgeo.p; v.vals = cvals.p; v.body = cbody.p; v.vel = vel.p; v.temp = temp.p; v.mass = mass.p;
             v.restitution = cfg.restitution;
             v.slot_state = slot_state_full ? slot_state.p : nullptr;
-#if defined(PSIM_HOSTLOOP)
-            be::launch(st, nH, v);
-#else
             be::launch_contact_rounds<false>(st, v, nH, prevl.p, done.p, r, round_tile_view());
-#endif
         }
         // ---- totals, log, write-back
         size_t log_cap = 0;

@@ -8,11 +8,13 @@
 #define PSIM_HD
 #define PSIM_FORCEINLINE inline
 #define PSIM_RESTRICT __restrict__
+#include "lane_hostloop.h"
 #else
 #include <hip/hip_runtime.h>
 #define PSIM_HD __host__ __device__
 #define PSIM_FORCEINLINE __forceinline__
 #define PSIM_RESTRICT __restrict__
+#include "lane_hip.h"
 #endif
 
 namespace psim {

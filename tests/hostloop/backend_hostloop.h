@@ -78,6 +78,14 @@ inline void band_select(Stream, const uint32_t*, uint64_t, int32_t, int32_t, int
     throw std::runtime_error("band_select: not in the host-loop build");
 }
 
+// the dependency rounds of the contact solver: one launch = one round, one element after the other
+struct RoundTiles { uint32_t* left; uint32_t* first; uint32_t* last; };
+template <bool POSITIONS, class Body>
+inline void launch_contact_rounds(Stream st, const Body& body, uint32_t n, const int32_t*, uint32_t*, uint32_t, const RoundTiles&)
+{
+    launch(st, (int64_t)n, body);
+}
+
 inline size_t sort_temp_words(uint64_t) { return 1; }
 inline uint32_t* lookback_fault_word() { static uint32_t zero = 0; return &zero; }
 template <class KeyT>
