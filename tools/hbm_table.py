@@ -29,7 +29,7 @@ ROWS = [
     ("DriftKeys", "DriftKeys (drift + Morton key + cell id + packed record)", 128),
     ("sort_pass_kernel<unsigned long, 16>", "Morton sort pass (u64 key + u32 index)", 24),
     ("sort_pass_kernel<unsigned int, 16>", "cell sort pass (u32 key + u32 index)", 16),
-    ("FixRuns", "FixRuns", 24),
+    ("FixRuns", "FixRuns (in place: keys read, only runs rewritten)", 8),
     ("GatherTree", "GatherTree (random 32 B gather)", 60),
     ("GatherCell", "GatherCell (random 32 B gather)", 72),
     ("HilbertCellRuns", "HilbertCellRuns", 8),
