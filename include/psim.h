@@ -242,7 +242,11 @@ int psim_pair_potential_energy_noalloc(psim_context* ctx, double* out);
  * psim_debug_size returns the element count (or < 0 for an unknown name);
  * psim_debug_fetch copies min(bytes, size) bytes.  Names: key perm L owned base
  * rec node_first node_last node_depth grid_offsets grid_indices cell_key
- * contact_ij contact_vals delta_temps exploded depth_offsets */
+ * contact_ij contact_vals delta_temps exploded depth_offsets.
+ * contact_ij / contact_vals (debug bit 0) hold one row per pair of the contact solver's settled
+ * list, in the reference's visiting order; a row of the list that is no contact of this context
+ * -- the pair did not touch when its turn came, or, in one rank's band of a split step, the
+ * contact is another rank's to count -- has both indices -1 and zeros for values. */
 int64_t psim_debug_size(psim_context* ctx, const char* name);
 int psim_debug_fetch(psim_context* ctx, const char* name, void* dst, size_t bytes);
 

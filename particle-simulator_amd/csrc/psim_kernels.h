@@ -1244,8 +1244,11 @@ struct ContactVelocity {
     PSIM_HD Pre prepare(int64_t h, uint32_t si, uint32_t sj) const
     {
         Pre p;
-        p.mi = mass[body[si].idx]; p.mj = mass[body[sj].idx];
         p.g[0] = geo[3 * h]; p.g[1] = geo[3 * h + 1]; p.g[2] = geo[3 * h + 2];
+        // (a pair that did not touch passes both states on as they are: its masses are not needed)
+        const bool touched = p.g[0] != 0.0 || p.g[1] != 0.0;
+        p.mi = touched ? mass[body[si].idx] : 1.0;
+        p.mj = touched ? mass[body[sj].idx] : 1.0;
         return p;
     }
     PSIM_HD State initial(uint32_t slot) const { return fetch(slot, -1); }
@@ -1716,8 +1719,8 @@ struct RetestPass {
     }
 };
 
-// every key of `a` occurs in the sorted, duplicate-free list `b` (binary search);
-// with equal lengths and duplicate-free `a` that makes the two lists equal as sets
+// every key of `a` occurs in the sorted, duplicate-free list `b` (binary search): `a` is a
+// subset of `b`, and with equal lengths and duplicate-free `a` the two are equal as sets
 struct AllFound {
     int64_t n;
     const uint64_t* a;
@@ -1754,7 +1757,9 @@ struct ResetSeg {
     PSIM_HD void operator()(int64_t e) const { cseg[(uint32_t)(adj[e] >> 32)] = -1; }
 };
 
-// converged: write each touched slot's final position back (index space + slot copy)
+// converged: write each touched slot's final position back (index space + slot copy).  The
+// settled list may hold pairs that did not touch when their turn came (geo = 0, 0: they left
+// both particles as they were); a slot none of whose pairs touched is not a touched slot.
 struct ContactFinalizePositions {
     int64_t n_adj;
     const uint64_t* adj;
@@ -1765,17 +1770,25 @@ struct ContactFinalizePositions {
     vec2* pos;
     uint8_t* moved;           // slot -> touched by a contact this step
     uint32_t* newly;          // [entry] 1 where a slot is touched for the first time this step
+    const double* geo;        // [3h]
     PSIM_HD void operator()(int64_t e) const
     {
         uint32_t x = (uint32_t)(adj[e] >> 32);
         bool last = (e + 1 == n_adj) || ((uint32_t)(adj[e + 1] >> 32) != x);
-        newly[e] = (last && moved[x] == 0) ? 1u : 0u;
+        newly[e] = 0u;
         if (!last) return;
+        cseg[x] = -1;
+        bool any = false;
+        for (int64_t k = e; k >= 0 && (uint32_t)(adj[k] >> 32) == x && !any; --k) {
+            uint32_t hk = (uint32_t)adj[k];
+            any = geo[3 * (size_t)hk] != 0.0 || geo[3 * (size_t)hk + 1] != 0.0;
+        }
+        if (!any) return;
+        newly[e] = moved[x] == 0 ? 1u : 0u;
         moved[x] = 1;
         uint32_t h = (uint32_t)adj[e];
         int side = (hsi[h] == x) ? 0 : 1;
         vec2 s = out[2 * h + side];
-        cseg[x] = -1;
         body[x].x = s.x;
         body[x].y = s.y;
         if (pos) pos[body[x].idx] = s;      // (null: the caller exports the touched slots' states instead)
@@ -1825,12 +1838,15 @@ struct ContactLog {
     // the lower-index particle, slot hsi) lies in the owned rows are counted and logged;
     // the others are counted by the neighbouring rank
     int32_t own_lo, own_hi;
-    uint32_t* owned_count;    // optional
+    uint32_t* owned_count;    // optional: number of contacts counted and logged
+    // the settled list may hold pairs that did not touch when their turn came (geo = 0, 0):
+    // they are no contacts, and are left out like the ones another rank counts
+    const double* geo;        // [3h]
     PSIM_HD void operator()(int64_t h) const
     {
         double pe = vals[3 * h], ke = vals[3 * h + 1], heat = vals[3 * h + 2];
         int32_t row = (int32_t)(body[hsi[h]].cxy >> 16);
-        bool own = row >= own_lo && row < own_hi;
+        bool own = row >= own_lo && row < own_hi && (geo[3 * h] != 0.0 || geo[3 * h + 1] != 0.0);
         sum_pe[h] = own ? pe : 0.0;
         sum_ke[h] = own ? ke : 0.0;
         sum_heat[h] = (own && heat > 0) ? heat : 0.0;
@@ -2105,6 +2121,8 @@ struct ExportDeltaWrite {
     }
 };
 // contacts of the settled list that involve a slot of row seam - 1 or row seam
+// (pairs of the list that did not touch when their turn came, geo = 0, 0, are no contacts: which
+// of them a rank's list holds depends on that rank's hypotheses, not on the state)
 struct SeamFlag {
     int64_t n;
     const uint32_t* hsi;
@@ -2112,10 +2130,12 @@ struct SeamFlag {
     const CellBody* body;
     int32_t seam;
     uint32_t* flag;
+    const double* geo;        // [3h]
     PSIM_HD void operator()(int64_t h) const
     {
         int32_t ri = (int32_t)(body[hsi[h]].cxy >> 16), rj = (int32_t)(body[hsj[h]].cxy >> 16);
-        flag[h] = (ri == seam || ri == seam - 1 || rj == seam || rj == seam - 1) ? 1u : 0u;
+        bool touched = geo[3 * h] != 0.0 || geo[3 * h + 1] != 0.0;
+        flag[h] = (touched && (ri == seam || ri == seam - 1 || rj == seam || rj == seam - 1)) ? 1u : 0u;
     }
 };
 struct SeamWrite {

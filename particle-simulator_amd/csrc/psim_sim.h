@@ -279,7 +279,7 @@ public:
     Lane side_lane() { return Lane{st2, &sort_tmp2, &scan_tmp2, counters2.p, &mailbox2, true}; }
     // what the position half leaves for the velocity half of the same sweep
     int rounds_hint = 6;               // dependency rounds launched before the first re-test of an iteration
-    uint32_t settled_contacts = 0, settled_rounds = 0;
+    uint32_t settled_contacts = 0, settled_touching = 0, settled_rounds = 0;
     uint64_t* settled_adj = nullptr;
     bool positions_settled = false;    // sweep 0's position half has run for this step
     uint32_t cond_ne = 0;              // conduction entries (sorted) waiting for ConductionApply
@@ -1001,7 +1001,7 @@ public:
         int hn_which = 0;
         uint32_t nH = n0;
         uint64_t* adjs = nullptr;
-        uint32_t round = 0, last_exec = 0;
+        uint32_t round = 0, last_exec = 0, nNewSettled = 0;
         // Incremental re-test: per slot a digest of its versioned positions in the previous
         // iteration (zero at the start and at the end of every sweep), a flag where this
         // iteration's differ, and the list of the previous iteration's touched slots.
@@ -1149,15 +1149,21 @@ public:
                     be::launch(ln.s, ntot, rp);
                 }
             }
-            // H' == H?  Both are duplicate-free, so equal length + every new key found in the
-            // (sorted) hypothesis means equal sets; the new list is only sorted if it is needed.
-            bool same = (nNew == nH);
+            // Settled when H' is a subset of H: the pairs of H that are not in H' did not touch
+            // when their turn came and changed nothing, so executing H' alone passes through the
+            // very same states -- H' is its own re-test, and this execution (labels, positions,
+            // normals) is already H's and its both.  The pairs that did not touch stay in the
+            // list as such (normal 0, 0): the velocity half passes them by, the log, the counts,
+            // the seam records and the list of touched slots leave them out.  Both lists are
+            // duplicate-free, so "every new key is found in the (sorted) hypothesis" is the subset
+            // test; the new list is only sorted if it is needed.
+            bool same = nNew > 0 && nNew <= nH;
             if (same) {
                 be::dev_memset(ln.s, ctr, 0, 4);
                 be::launch(ln.s, nNew, AllFound{(int64_t)nNew, hn[0].p, H, (int64_t)nH, ctr});
                 same = read_u32(ln, ctr) == 0;
             }
-            if (same) break;
+            if (same) { nNewSettled = nNew; break; }
             uint64_t* kn[2] = {hn[0].p, hn[1].p};
             hn_which = be::radix_sort_pairs<uint64_t>(ln.s, kn, nullptr, nNew, 0, key_bits, ln.sort_tmp->p);
             // this iteration's digests become the ones the next compares with; flags and segment starts cleared
@@ -1178,13 +1184,14 @@ public:
         pcount.ensure(2 * (size_t)nH); poffs.ensure(2 * (size_t)nH);
         ContactFinalizePositions f;
         f.n_adj = 2ll * nH; f.adj = adjs; f.cseg = cseg.p; f.hsi = hsi.p; f.out = outp.p; f.body = cbody.p;
-        f.pos = deferred ? nullptr : pos.p; f.moved = moved.p; f.newly = pcount.p;
+        f.pos = deferred ? nullptr : pos.p; f.moved = moved.p; f.newly = pcount.p; f.geo = cgeo.p;
         be::launch(ln.s, 2ll * nH, f);
         be::exclusive_scan_u32(ln.s, pcount.p, poffs.p, 2ull * nH, scan_scratch.p, ctr + 5, small_groups_now(ln.small_groups));
         be::launch(ln.s, 2ll * nH, WriteMoved{2ll * nH, adjs, pcount.p, poffs.p, moved_list.p + n_moved});
         // (ContactFinalizePositions has already marked every touched slot clean again)
         n_moved += read_u32(ln, ctr + 5);
-        settled_contacts = nH; settled_rounds = last_exec; settled_adj = adjs;
+        // (H' is a subset of H and holds exactly the pairs of H that touched)
+        settled_contacts = nH; settled_touching = nNewSettled; settled_rounds = last_exec; settled_adj = adjs;
     }
 
     // velocity half of the sweep whose position half ran last (main stream)
@@ -1228,6 +1235,7 @@ public:
         cl.sum_pe = sum_pe.p; cl.sum_ke = sum_ke.p; cl.sum_heat = sum_heat.p;
         cl.own_lo = deferred ? band.own_lo : 0; cl.own_hi = deferred ? band.own_hi : cfg.grid_h;
         cl.owned_count = deferred ? step_words.p + 8 : nullptr;
+        cl.geo = cgeo.p;
         if (deferred) be::dev_memset(st, step_words.p + 8, 0, 16);
         be::launch(st, nH, cl);
         const bool last_sweep = sweep + 1 >= cfg.solver_iterations;
@@ -1249,7 +1257,7 @@ public:
             for (int k = 0; k < 2; ++k) {
                 if (seams[k] <= 0 || seams[k] >= cfg.grid_h) continue;       // the domain's edge: no neighbour
                 any = true;
-                be::launch(st, nH, SeamFlag{(int64_t)nH, hsi.p, hsj.p, cbody.p, seams[k], pcount.p + (size_t)k * nH});
+                be::launch(st, nH, SeamFlag{(int64_t)nH, hsi.p, hsj.p, cbody.p, seams[k], pcount.p + (size_t)k * nH, cgeo.p});
                 be::exclusive_scan_u32(st, pcount.p + (size_t)k * nH, poffs.p + (size_t)k * nH, nH, scan_tmp.p, step_words.p + 9 + k);
             }
             uint32_t w[3];
@@ -1270,7 +1278,7 @@ public:
                 seam_n[k] += add;
             }
         } else {
-            n_contacts += nH;
+            n_contacts += settled_touching;
         }
         if (last_sweep) {
             totals_pending = true;       // fetched with the explosion count (walls_and_flags) or by the export

@@ -443,7 +443,7 @@ class ParticleSystem:
         a.flags.writeable = False
         return a
 
-    def debug_array(self, name):
+    def debug_array(self, name, holes=False):
         self._sync_state()
         dtype, tail = self._DEBUG_DTYPES[name]
         cnt = int(self._lib.psim_debug_size(self._ctx, name.encode()))
@@ -452,6 +452,12 @@ class ParticleSystem:
         out = np.empty((cnt,) + tail, dtype=dtype)
         _capi.check(self._lib, self._lib.psim_debug_fetch(self._ctx, name.encode(),
                                                           out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        if name == "contact_vals":
+            return out[self.debug_array("contact_ij", holes=True)[:, 0] >= 0]
+        if name == "contact_ij" and not holes:
+            # rows of -1: pairs of the solver's list that did not touch when their turn came, or
+            # (one rank's band of a split step) contacts another rank counts
+            return out[out[:, 0] >= 0]
         return out
 
     def canonical_tree(self):
