@@ -235,3 +235,22 @@ def test_deep_chains_across_tiles_vs_oracle():
     n, bounds = 30000, (2000.0, 1000.0)
     st = parity.tight_pairs_state(n, bounds, 4, pairs=60, gap=1e-3, box=900.0)
     parity.check_tree_against_oracle(HIP, st, n, bounds, expect_path=1)
+
+
+def test_settled_list_with_pairs_that_did_not_touch_vs_oracle():
+    """a clumped state: the first hypothesis reaches beyond contact distance and the sweep settles on a
+    list that still holds the pairs that did not touch (rows of -1 in the raw log); contacts, counts
+    and states are the oracle's all the same, and such rows do occur"""
+    n, bounds = 40000, (3400, 2500)
+    parity.run_against_oracle(n, SIM, 3, bounds, 4, HIP)
+    s = ParticleSystem(n, dict(SIM), np.random.default_rng(3), bounds, library=HIP, debug=1)
+    s._calculate_gravity()
+    held = 0
+    for _ in range(4):
+        s.update()
+        raw = s.debug_array("contact_ij", holes=True)
+        kept = s.debug_array("contact_ij")
+        assert len(kept) == s.counts()["contacts"] == len(s.debug_array("contact_vals"))
+        held += len(raw) - len(kept)
+    assert held > 0
+    s.close()

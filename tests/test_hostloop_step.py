@@ -213,3 +213,23 @@ def test_reference_attributes_and_the_diagnostic_getters():
     assert p["uniform_accept_trips"] + p["uniform_open_trips"] + p["box_accept_trips"] + p["box_open_trips"] \
         + p["full_trips"] <= p["trips"]
     s.close()
+
+
+def test_settled_list_with_pairs_that_did_not_touch_vs_oracle():
+    """a clumped state switches the first hypothesis' margin on; the sweep then settles on a list
+    that still holds the pairs that did not touch (rows of -1 in the raw log): contacts, counts and
+    states must be the oracle's all the same, and such rows must really occur in this case"""
+    n, bounds = 4000, (1100, 800)
+    parity.run_against_oracle(n, SIM, 3, bounds, 4, HOSTLOOP)
+    s = ParticleSystem(n, dict(SIM), np.random.default_rng(3), bounds, library=HOSTLOOP, debug=1)
+    s._calculate_gravity()
+    held = 0
+    for _ in range(4):
+        s.update()
+        raw = s.debug_array("contact_ij", holes=True)
+        kept = s.debug_array("contact_ij")
+        assert len(kept) == s.counts()["contacts"] == len(s.debug_array("contact_vals"))
+        assert np.all(kept >= 0)
+        held += len(raw) - len(kept)
+    assert held > 0
+    s.close()
