@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long run of the benchmark workload: the state evolves (particles clump, contact chains
 get deeper), so the solver's iteration and round counts and the step time are printed as it goes.
-usage: long_run.py [steps] [workload]"""
+usage: long_run.py [steps] [workload] [library]"""
 import os
 import sys
 import time
@@ -15,7 +15,8 @@ from psim_amd.particle_system import ParticleSystem
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 label, n, bounds, state, mask = bench.workload(sys.argv[2] if len(sys.argv) > 2 else "c2")
-ps = ParticleSystem(n, dict(bench.SIM), np.random.default_rng(42), bounds, stage_mask=mask, state=state)
+ps = ParticleSystem(n, dict(bench.SIM), np.random.default_rng(42), bounds, stage_mask=mask, state=state,
+                    library=sys.argv[3] if len(sys.argv) > 3 else None)
 ps._calculate_gravity()
 e0 = ps.get_energies()
 t0 = time.time()
