@@ -241,7 +241,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    on_gpu = args.library is None or args.backend == "nccl"
+    on_gpu = args.library is None or args.backend == "nccl" or os.path.basename(args.library).startswith("libpsim_hip")
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")

@@ -146,6 +146,8 @@ int64_t psim_particle_updates(psim_context* ctx);
  * Results are bit-identical to psim_step for any number of ranks and any bands that tile the
  * grid rows (halo >= 2 rows on either side of the own rows, clipped to the grid), except the
  * three collision totals, which are sums of the ranks' partial sums.
+ * acc_sorted, block and blocks are memory the GPU works on directly: device memory or
+ * page-locked host memory; any other pointer is PSIM_ERR_INVALID (checked before a kernel sees it).
  * psim_stage_stats: [0] steps that took the fallback so far, [1] particles in the own rows of
  * the last band, [2] particles in the last band, [3] words of a block's header. */
 int psim_stage_build(psim_context* ctx);
@@ -251,7 +253,8 @@ int64_t psim_debug_size(psim_context* ctx, const char* name);
 int psim_debug_fetch(psim_context* ctx, const char* name, void* dst, size_t bytes);
 
 /* self-test of the device primitives (radix sort, scan, reduction) on n seeded
- * items against host results; 0 = all matched */
+ * items against host results, and of the check that tells memory the GPU can reach from
+ * ordinary host memory; 0 = all matched */
 int psim_selftest(int device_ordinal, int64_t n, uint64_t seed);
 
 /* timing hook for benchmarks: device-side duration in milliseconds of each

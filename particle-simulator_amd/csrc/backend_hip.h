@@ -765,6 +765,40 @@ __global__ void __launch_bounds__(256) sort_one_tile_kernel(const KeyT* kin, con
     }
 }
 
+// A pointer handed in by the caller for kernels to work on: device memory or page-locked host
+// memory.  Anything else (an ordinary host pointer) would end in a GPU memory fault.
+inline void require_device_memory(const void* p, const char* what)
+{
+    hipPointerAttribute_t a;
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) (void)hipGetLastError();
+    if (e != hipSuccess || a.type == hipMemoryTypeUnregistered)
+        throw std::invalid_argument(std::string("psim: ") + what +
+                                    " must be device memory or page-locked host memory (the GPU cannot reach this pointer)");
+}
+
+// (self-test) the three kinds of memory a caller might hand in, classified without a kernel
+// touching any of them
+inline void selftest_pointer_kinds()
+{
+    std::vector<char> plain(4096);
+    void* dev = nullptr;
+    void* pinned = nullptr;
+    PSIM_HIP(hipMalloc(&dev, 4096));
+    PSIM_HIP(hipHostMalloc(&pinned, 4096, hipHostMallocDefault));
+    bool refused = false;
+    try { require_device_memory(plain.data() + 64, "selftest"); } catch (const std::invalid_argument&) { refused = true; }
+    std::string bad;
+    try {
+        require_device_memory(static_cast<char*>(dev) + 64, "selftest: device memory");
+        require_device_memory(static_cast<char*>(pinned) + 64, "selftest: page-locked memory");
+    } catch (const std::invalid_argument& e) { bad = e.what(); }
+    (void)hipFree(dev);
+    (void)hipHostFree(pinned);
+    if (!refused) throw std::runtime_error("selftest: an ordinary host pointer passed for memory the GPU can reach");
+    if (!bad.empty()) throw std::runtime_error("selftest: refused: " + bad);
+}
+
 inline size_t sort_temp_words(uint64_t n)
 {
     // enough for any input of at most n keys, whichever tiling it gets

@@ -237,6 +237,7 @@ int psim_stage_gravity(psim_context* ctx, int64_t s_lo, int64_t s_hi, double* ac
     // not waited for: the caller's exchange is ordered after the walk on the same stream
     PSIM_TRY(ctx && acc_sorted, {
         use_device(ctx->device);
+        psim::be::require_device_memory(acc_sorted, "psim_stage_gravity: acc_sorted");
         ctx->sim->stage_gravity(s_lo, s_hi, reinterpret_cast<psim::vec2*>(acc_sorted));
     })
 }
@@ -253,6 +254,7 @@ int psim_stage_kick(psim_context* ctx, const double* acc_sorted)
 {
     PSIM_TRY(ctx && acc_sorted, {
         use_device(ctx->device);
+        psim::be::require_device_memory(acc_sorted, "psim_stage_kick: acc_sorted");
         ctx->sim->stage_kick(reinterpret_cast<const psim::vec2*>(acc_sorted));
     })
 }
@@ -269,6 +271,7 @@ int psim_stage_slab_export(psim_context* ctx, uint64_t* block, int64_t cap_words
 {
     PSIM_TRY(ctx && block && words_needed, {
         use_device(ctx->device);
+        psim::be::require_device_memory(block, "psim_stage_slab_export: block");
         *words_needed = ctx->sim->slab_export(block, cap_words);
     })
 }
@@ -278,6 +281,7 @@ int psim_stage_apply(psim_context* ctx, const uint64_t* blocks, int32_t world, i
 {
     PSIM_TRY(ctx && blocks && status, {
         use_device(ctx->device);
+        psim::be::require_device_memory(blocks, "psim_stage_apply: blocks");
         *status = ctx->sim->stage_apply(blocks, world, block_words, own_slots, words_needed);
     })
 }
@@ -641,6 +645,7 @@ int psim_selftest(int device_ordinal, int64_t n, uint64_t seed)
         use_device(device_ordinal);
         using namespace psim;
         be::Stream st = 0;
+        be::selftest_pointer_kinds();
         std::mt19937_64 rng(seed);
         size_t c = (size_t)n;
         // --- u64 sort with payload, all 64 bits, duplicates forced

@@ -93,7 +93,8 @@ class ShardedParticleSystem(ParticleSystem):
         else:
             self._rank = dist.get_rank(group)
             self._world = dist.get_world_size(group)
-        on_gpu = kw.get("library") is None
+        # (asked of the library itself: the pointers it is handed must be of the memory it works on)
+        on_gpu = b"HIP" in self._lib.psim_version()
         self._tdev = torch.device("cuda", self._device) if on_gpu else torch.device("cpu")
         # how the exchanged buffers travel: "device" = the collective works on the device
         # tensors (RCCL); "host" = through page-locked host copies (any backend that moves CPU

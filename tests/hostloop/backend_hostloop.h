@@ -86,6 +86,8 @@ inline void launch_contact_rounds(Stream st, const Body& body, uint32_t n, const
     launch(st, (int64_t)n, body);
 }
 
+inline void selftest_pointer_kinds() {}
+inline void require_device_memory(const void*, const char*) {}      // (all memory is host memory here)
 inline size_t sort_temp_words(uint64_t) { return 1; }
 inline uint32_t* lookback_fault_word() { static uint32_t zero = 0; return &zero; }
 template <class KeyT>

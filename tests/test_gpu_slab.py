@@ -77,3 +77,24 @@ def test_c3_16Mi_eight_bands_equal_the_unsharded_step():
                               init_velocities=lambda: None, state=state)
     fallbacks, contacts = sc.run_emulated(None, c, 8, 1, ranks=[5])
     assert fallbacks == 0 and contacts > 100000
+
+
+def test_staged_entry_points_refuse_ordinary_host_pointers():
+    """the staged calls take device (or page-locked) pointers; an ordinary host array must come back
+    as an error before any kernel is handed its address"""
+    import ctypes
+    from psim_amd import _capi
+    from psim_amd.particle_system import ParticleSystem
+    n = 2000
+    # (first the check by itself, on buffers no kernel touches)
+    assert _capi.load().psim_selftest(0, 1000, 1) == 0, _capi.load().psim_last_error().decode()
+    s = ParticleSystem(n, dict(bench.SIM), np.random.default_rng(1), (2000, 1000))
+    s._calculate_gravity()
+    L, ctx = s._lib, s._ctx
+    _capi.check(L, L.psim_stage_build(ctx))
+    host = np.zeros((n, 2))
+    rc = L.psim_stage_gravity(ctx, 0, n, ctypes.c_void_p(host.ctypes.data))
+    assert rc == -1 and b"page-locked" in L.psim_last_error()
+    with pytest.raises(ValueError):
+        _capi.check(L, L.psim_stage_kick(ctx, ctypes.c_void_p(host.ctypes.data)))
+    s.close()

@@ -17,7 +17,7 @@ from psim_amd.distributed import ShardedParticleSystem
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 first = int(args[0]) if args else 0
 count = int(args[1]) if len(args) > 1 else 20
-lib = _capi.HIP_LIBRARY if "--hip" in sys.argv else os.path.join(ROOT, "tests", "hostloop", "libpsim_hostloop.so")
+lib = _capi.HIP_LIBRARY if "--hip" in sys.argv else os.environ.get("PSIM_FUZZ_LIBRARY", os.path.join(ROOT, "tests", "hostloop", "libpsim_hostloop.so"))
 BASE = dict(particle_count=0, min_mass=5.0, max_mass=20.0, gravity_constant=0.01, softening_factor=10,
             barnes_hut_theta=0.5, min_temp=0.05, max_temp=0.1, heat_transfer_coefficient=0.1,
             coefficient_of_restitution=0.5, grid_cell_size_multiplier=10.0, position_correction_factor=1.05,
