@@ -180,11 +180,18 @@ inline void delay(Stream st, uint32_t microseconds)
 // functor launched this way uses LDS or a barrier; wave-level operations are all they share.
 // With the device to itself a launch of millions of lanes is dispatched faster in workgroups
 // of four waves (7 M lanes: 260 against 140 us for the short kernels of the contact solver),
-// so the caller says which situation it is in: wide_groups() = no walk in flight.
+// so the caller says which situation it is in: wide_groups() = no walk in flight.  Only the
+// stream that works beside the walk (narrow_stream()) is concerned: what is queued on the walk's
+// own stream runs when the walk has ended, whenever it is submitted.
 inline bool& wide_groups()
 {
     static thread_local bool wide = false;
     return wide;
+}
+inline Stream& narrow_stream()
+{
+    static thread_local Stream s = nullptr;
+    return s;
 }
 template <class F, int LANES>
 __global__ void __launch_bounds__(LANES) psim_kernel(int64_t n, F f)
@@ -197,7 +204,7 @@ template <class F>
 inline void launch(Stream st, int64_t n, const F& f)
 {
     if (n <= 0) return;
-    const int lanes = wide_groups() ? 256 : 64;
+    const int lanes = (wide_groups() || st != narrow_stream()) ? 256 : 64;
     int64_t blocks = (n + lanes - 1) / lanes;
     if (blocks > 0x7fffffffLL) throw std::runtime_error("launch: grid too large");
     if (lanes == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(psim_kernel<F, 256>), dim3((unsigned)blocks), dim3(256), 0, st, n, f);

@@ -263,6 +263,7 @@ public:
     void refresh_groups()
     {
         if (walk_in_flight && be::event_done(ev_walk())) walk_in_flight = false;
+        be::narrow_stream() = st2;
         be::wide_groups() = !walk_in_flight;
     }
     // A lane = a stream with the scratch its sorts, scans and small readbacks use.  The
@@ -1599,6 +1600,7 @@ public:
         timer.mark(st, 4);             // (also the walk's end, as the host and the side lane ask for it)
         be::launch(st, n, Kick{n, vel.p, acc.p, acc2.p});      // (runs when the walk has ended)
         walk_in_flight = true;
+        be::narrow_stream() = st2;
         be::wide_groups() = false;
         acc.swap(acc2);
         if (side) start_side_work();
@@ -1642,6 +1644,7 @@ public:
         gravity_range(lo, hi, acc_sorted, true);
         timer.mark(st, 4);
         walk_in_flight = hi > lo;
+        be::narrow_stream() = st2;
         be::wide_groups() = !walk_in_flight;
     }
     // The half of the collision stage that needs no velocities, for the band of grid rows

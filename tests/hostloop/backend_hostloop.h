@@ -49,6 +49,7 @@ inline void mailbox_fetch(Stream, Mailbox&, void* dst, const void* a, uint32_t n
     if (nb) memcpy((char*)dst + (size_t)na * 4, b, (size_t)nb * 4);
 }
 
+inline Stream& narrow_stream() { static Stream s = 0; return s; }
 inline bool& wide_groups()
 {
     static bool wide = false;
